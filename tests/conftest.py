@@ -1,0 +1,47 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_bin():
+    """oracle/cfr_oracle (the plain-C restatement CLI); built on demand with gcc."""
+    exe = os.path.join(ORACLE_DIR, "cfr_oracle")
+    src_newer = (not os.path.exists(exe)) or any(
+        os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(exe)
+        for f in ("cfr_oracle.c", "cfr_oracle.h", "cfr_oracle_main.c"))
+    if src_newer:
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
+    return exe
+
+
+@pytest.fixture(scope="session")
+def golden_dir(tmp_path_factory):
+    """tests/golden with f10.1.cfr gunzipped into a temp dir (symlinks for the rest)."""
+    import gzip
+    import shutil
+    d = tmp_path_factory.mktemp("golden")
+    for f in os.listdir(GOLDEN):
+        src = os.path.join(GOLDEN, f)
+        if f.endswith(".cfr.gz"):
+            with gzip.open(src, "rb") as fi, open(d / f[:-3], "wb") as fo:
+                shutil.copyfileobj(fi, fo)
+        elif os.path.isfile(src):
+            os.symlink(src, d / f)
+    return str(d)
+
+
+def have_ref():
+    return all(os.path.exists(os.path.join(REF_DIR, b)) for b in ("centrifuger", "centrifuger-build"))
