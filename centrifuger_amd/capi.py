@@ -1,0 +1,272 @@
+"""ctypes binding of libcfr_hip.so (include/cfr_hip.h).  Thin: numpy arrays in, numpy arrays out.
+
+The library is the product; there is no Python/CPU fallback here - if the shared object is
+missing or no HIP device is usable, calls raise CfrError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfr_hip.so")
+
+CFR_OK, CFR_ERR_IO, CFR_ERR_FORMAT, CFR_ERR_NO_DEVICE, CFR_ERR_HIP, CFR_ERR_ARG, CFR_ERR_CAPACITY = range(7)
+
+
+class CfrError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"cfr status {status}: {msg}")
+        self.status = status
+
+
+class Params(C.Structure):
+    _fields_ = [("max_result", C.c_int32), ("min_hit_len", C.c_int32), ("max_result_per_hit_factor", C.c_int32),
+                ("reserved", C.c_int32), ("consider_secondary_hit_len", C.c_uint64),
+                ("consider_secondary_score_factor", C.c_double)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("first_isa", C.c_uint64), ("block_size", C.c_uint64), ("precompute_width", C.c_uint64),
+                ("sample_rate", C.c_uint64), ("selected_cnt", C.c_uint64), ("seq_cnt", C.c_uint64), ("node_cnt", C.c_uint64),
+                ("min_hit_len", C.c_int32), ("last_chr", C.c_char), ("pad", C.c_char * 3), ("device_bytes", C.c_uint64)]
+
+
+class BatchStats(C.Structure):
+    _fields_ = [("pack_ms", C.c_float), ("search_ms", C.c_float), ("adjust_ms", C.c_float), ("rows_ms", C.c_float),
+                ("locate_ms", C.c_float), ("tail_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_chains", C.c_uint64), ("n_hits", C.c_uint64), ("n_rows", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("sp", "<u8"), ("ep", "<u8"), ("l", "<i4"), ("strand", "<i4"), ("offset", "<i4"), ("pad", "<i4")])
+RESULT_DTYPE = np.dtype([("score", "<u8"), ("secondary_score", "<u8"), ("hit_length", "<i4"), ("query_length", "<i4"),
+                         ("n_match", "<i4"), ("pad", "<i4"), ("match_begin", "<u8")])
+MATCH_DTYPE = np.dtype([("id", "<u8"), ("taxid", "<u8"), ("kind", "<i4"), ("pad", "<i4")])
+
+EXPORTS = [
+    "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
+    "cfr_device_count", "cfr_device_index_create", "cfr_device_index_destroy", "cfr_device_index_get_info",
+    "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
+    "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
+    "cfr_format_tsv", "cfr_tsv_header",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CfrError(-1, f"{LIB_PATH} not built (run `python -c 'import __graft_entry__ as g; g.build()'` or make -C centrifuger_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        L.cfr_last_error.restype = C.c_char_p
+        L.cfr_version.restype = C.c_char_p
+        L.cfr_tsv_header.restype = C.c_char_p
+        L.cfr_format_tsv.restype = C.c_size_t
+        for name in EXPORTS:
+            if name not in ("cfr_last_error", "cfr_version", "cfr_tsv_header", "cfr_format_tsv", "cfr_index_destroy",
+                            "cfr_device_index_destroy", "cfr_params_default"):
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _check(status):
+    if status != CFR_OK:
+        raise CfrError(status, lib().cfr_last_error().decode())
+
+
+def _p(a, t=C.c_void_p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().cfr_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _u64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class Index:
+    """cfr_index: host copy of <prefix>.{1,2,4}.cfr (Classifier::Init, Classifier.hpp:902-947)."""
+
+    def __init__(self, prefix: str, params: Params | None = None):
+        self._h = C.c_void_p()
+        self.params = params if params is not None else default_params()
+        _check(lib().cfr_index_open(prefix.encode(), C.byref(self.params), C.byref(self._h)))
+
+    def info(self) -> IndexInfo:
+        info = IndexInfo()
+        _check(lib().cfr_index_get_info(self._h, C.byref(info)))
+        return info
+
+    def close(self):
+        if self._h:
+            lib().cfr_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def format_tsv(self, read_id: str, result, matches) -> bytes:
+        r = np.ascontiguousarray(result).reshape(1)
+        buf = C.create_string_buffer(1 << 16)
+        n = lib().cfr_format_tsv(self._h, read_id.encode(), _p(r), _p(matches), buf, C.c_size_t(len(buf)))
+        if n >= len(buf):
+            buf = C.create_string_buffer(n + 1)
+            lib().cfr_format_tsv(self._h, read_id.encode(), _p(r), _p(matches), buf, C.c_size_t(len(buf)))
+        return buf.raw[:n]
+
+    def classify_from_hits(self, hits, hit_begin, row_begin, row_vals, query_len, threads=1):
+        n = len(hit_begin) - 1
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        hit_begin, row_begin, row_vals = _u64(hit_begin), _u64(row_begin), _u64(row_vals)
+        query_len = np.ascontiguousarray(query_len, dtype=np.int32)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = max(16, 4 * n)
+        while True:
+            matches = np.zeros(cap, dtype=MATCH_DTYPE)
+            nm = C.c_size_t(0)
+            st = lib().cfr_classify_from_hits(self._h, _p(hits), _p(hit_begin), _p(row_begin), _p(row_vals), _p(query_len),
+                                              C.c_size_t(n), C.c_int(threads), _p(results), _p(matches), C.c_size_t(cap), C.byref(nm))
+            if st == CFR_ERR_CAPACITY:
+                cap = int(nm.value) + 16
+                continue
+            _check(st)
+            return results, matches[:nm.value]
+
+
+class DeviceIndex:
+    """cfr_dev_index: the flat index image in one GPU's HBM + the batch entry points."""
+
+    def __init__(self, index: Index, device: int = 0):
+        self.index = index
+        self._d = C.c_void_p()
+        _check(lib().cfr_device_index_create(index._h, C.c_int(device), C.byref(self._d)))
+
+    def info(self) -> IndexInfo:
+        info = IndexInfo()
+        _check(lib().cfr_device_index_get_info(self._d, C.byref(info)))
+        return info
+
+    def close(self):
+        if self._d:
+            lib().cfr_device_index_destroy(self._d)
+            self._d = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- probes
+    def rank(self, chars, pos, inclusive):
+        chars = np.ascontiguousarray(np.frombuffer(chars, dtype=np.uint8) if isinstance(chars, (bytes, bytearray)) else chars, dtype=np.uint8)
+        pos, inclusive = _u64(pos), _u8(inclusive)
+        n = len(pos)
+        out_r = np.zeros(n, dtype=np.uint64)
+        out_a = np.zeros(n, dtype=np.uint8)
+        _check(lib().cfr_rank_batch(self._d, _p(chars), _p(pos), _p(inclusive), C.c_size_t(n), _p(out_r), _p(out_a)))
+        return out_r, out_a
+
+    def backward_search(self, bases, offsets, m):
+        bases, offsets = _u8(bases), _u64(offsets)
+        m = np.ascontiguousarray(m, dtype=np.uint32)
+        n = len(m)
+        l, sp, ep = (np.zeros(n, dtype=np.uint64) for _ in range(3))
+        _check(lib().cfr_backward_search_batch(self._d, _p(bases), _p(offsets), _p(m), C.c_size_t(n), _p(l), _p(sp), _p(ep)))
+        return l, sp, ep
+
+    def locate(self, rows):
+        rows = _u64(rows)
+        n = len(rows)
+        val = np.zeros(n, dtype=np.uint64)
+        steps = np.zeros(n, dtype=np.uint32)
+        _check(lib().cfr_locate_rows(self._d, _p(rows), C.c_size_t(n), _p(val), _p(steps)))
+        return val, steps
+
+    # ---- the path
+    def search(self, bases1, offsets1, bases2=None, offsets2=None):
+        bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
+        n = len(offsets1) - 1
+        hit_begin = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(64, 16 * n)
+        while True:
+            hits = np.zeros(cap, dtype=HIT_DTYPE)
+            st = lib().cfr_search_batch(self._d, _p(bases1), _p(offsets1), _p(bases2), _p(offsets2), C.c_size_t(n),
+                                        _p(hits), C.c_size_t(cap), _p(hit_begin))
+            if st == CFR_ERR_CAPACITY:
+                cap = int(hit_begin[n]) + 16
+                continue
+            _check(st)
+            return hits[:int(hit_begin[n])], hit_begin
+
+    def classify(self, bases1, offsets1, bases2=None, offsets2=None):
+        bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
+        n = len(offsets1) - 1
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = max(16, 2 * n)
+        while True:
+            matches = np.zeros(cap, dtype=MATCH_DTYPE)
+            nm = C.c_size_t(0)
+            st = lib().cfr_classify_batch(self._d, _p(bases1), _p(offsets1), _p(bases2), _p(offsets2), C.c_size_t(n),
+                                          _p(results), _p(matches), C.c_size_t(cap), C.byref(nm))
+            if st == CFR_ERR_CAPACITY:
+                cap = int(nm.value) + 16
+                continue
+            _check(st)
+            return results, matches[:nm.value]
+
+    def classify_resident(self, d_bases1: int, d_offsets1: int, n: int, total1: int, d_bases2: int = 0, d_offsets2: int = 0,
+                          total2: int = 0, results=None, matches=None):
+        """Device pointers in (ints), host numpy out.  Caller must have synchronised the producer stream."""
+        if results is None:
+            results = np.zeros(n, dtype=RESULT_DTYPE)
+        if matches is None:
+            matches = np.zeros(max(16, 2 * n), dtype=MATCH_DTYPE)
+        nm = C.c_size_t(0)
+        st = lib().cfr_classify_batch_resident(self._d, C.c_void_p(d_bases1), C.c_void_p(d_offsets1),
+                                               C.c_void_p(d_bases2 or None), C.c_void_p(d_offsets2 or None), C.c_size_t(n),
+                                               C.c_uint64(total1), C.c_uint64(total2), _p(results), _p(matches),
+                                               C.c_size_t(len(matches)), C.byref(nm))
+        _check(st)
+        return results, matches[:nm.value]
+
+    def last_stats(self) -> BatchStats:
+        st = BatchStats()
+        _check(lib().cfr_last_batch_stats(self._d, C.byref(st)))
+        return st
+
+
+def device_count() -> int:
+    c = C.c_int(0)
+    st = lib().cfr_device_count(C.byref(c))
+    return c.value if st == CFR_OK else 0
+
+
+def dust_mask(bases, offsets, threads=1):
+    """In-place SDUST masking of a flat read buffer (cfr_dust_mask_batch)."""
+    assert bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"] and bases.flags["WRITEABLE"]
+    offsets = _u64(offsets)
+    _check(lib().cfr_dust_mask_batch(_p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.c_int(threads)))
+    return bases
+
+
+def tsv_header() -> bytes:
+    return lib().cfr_tsv_header()

@@ -1,0 +1,230 @@
+// cfr_capi.cpp — the extern "C" surface declared in include/cfr_hip.h.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+
+#include "cfr_device.hpp"
+#include "cfr_tail.hpp"
+
+struct cfr_index { cfr::HostIndex *h; };
+struct cfr_dev_index { cfr::DeviceIndex *d; const cfr_index *host; int tail_threads; };
+
+namespace {
+thread_local std::string g_err;
+
+template <class F> cfr_status guarded(F &&f) {
+  try {
+    return f();
+  } catch (const cfr::IoError &e) {
+    g_err = e.msg; return CFR_ERR_IO;
+  } catch (const cfr::FormatError &e) {
+    g_err = e.msg; return CFR_ERR_FORMAT;
+  } catch (const cfr::HipError &e) {
+    g_err = e.msg; return e.code == -1 ? CFR_ERR_NO_DEVICE : CFR_ERR_HIP;
+  } catch (const std::exception &e) {
+    g_err = e.what(); return CFR_ERR_ARG;
+  }
+}
+cfr_status bad_arg(const char *m) { g_err = m; return CFR_ERR_ARG; }
+
+void fill_info(const cfr::HostIndex &h, cfr_index_info *info, uint64_t dev_bytes) {
+  memset(info, 0, sizeof(*info));
+  info->n = h.n; info->first_isa = h.first_isa; info->block_size = h.b; info->precompute_width = h.precompute_width;
+  info->sample_rate = (uint64_t)h.sample_rate; info->selected_cnt = h.selected_rows.size();
+  info->seq_cnt = h.tax.seq_cnt; info->node_cnt = h.tax.node_cnt; info->min_hit_len = h.params.min_hit_len;
+  info->last_chr = h.last_chr; info->device_bytes = dev_bytes;
+}
+
+int default_tail_threads() {
+  unsigned hc = std::thread::hardware_concurrency();
+  if (hc == 0) hc = 1;
+  return (int)std::min(hc, 64u);
+}
+}  // namespace
+
+extern "C" {
+
+void cfr_params_default(cfr_params *p) {   // _classifierParam() (Classifier.hpp:28-37)
+  p->max_result = 1; p->min_hit_len = 0; p->max_result_per_hit_factor = 40; p->reserved = 0;
+  p->consider_secondary_hit_len = 2000; p->consider_secondary_score_factor = 0.995;
+}
+const char *cfr_last_error(void) { return g_err.c_str(); }
+const char *cfr_version(void) { return "centrifuger_amd 0.1 (gfx950); path parity with Centrifuger v1.1.3-r347"; }
+
+cfr_status cfr_index_open(const char *idx_prefix, const cfr_params *params, cfr_index **out) {
+  if (!idx_prefix || !out) return bad_arg("cfr_index_open: null argument");
+  return guarded([&]() -> cfr_status {
+    cfr::HostIndex *h = cfr::load_index(idx_prefix, params);
+    *out = new cfr_index{h};
+    return CFR_OK;
+  });
+}
+void cfr_index_destroy(cfr_index *idx) { if (idx) { delete idx->h; delete idx; } }
+cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info) {
+  if (!idx || !info) return bad_arg("cfr_index_get_info: null argument");
+  fill_info(*idx->h, info, 0);
+  return CFR_OK;
+}
+
+cfr_status cfr_device_count(int *count) {
+  if (!count) return bad_arg("cfr_device_count: null argument");
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) { *count = 0; g_err = "hipGetDeviceCount failed"; return CFR_ERR_NO_DEVICE; }
+  *count = c;
+  return CFR_OK;
+}
+cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out) {
+  if (!idx || !out) return bad_arg("cfr_device_index_create: null argument");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex *d = new cfr::DeviceIndex(*idx->h, device);
+    *out = new cfr_dev_index{d, idx, default_tail_threads()};
+    return CFR_OK;
+  });
+}
+void cfr_device_index_destroy(cfr_dev_index *d) { if (d) { delete d->d; delete d; } }
+cfr_status cfr_device_index_get_info(const cfr_dev_index *d, cfr_index_info *info) {
+  if (!d || !info) return bad_arg("cfr_device_index_get_info: null argument");
+  fill_info(d->d->host(), info, d->d->device_bytes());
+  return CFR_OK;
+}
+
+cfr_status cfr_rank_batch(cfr_dev_index *d, const char *chars, const uint64_t *pos, const uint8_t *inclusive, size_t n,
+                          uint64_t *out_rank, char *out_access) {
+  if (!d || (n && (!chars || !pos || !inclusive))) return bad_arg("cfr_rank_batch: null argument");
+  for (size_t i = 0; i < n; ++i) if (pos[i] >= d->d->host().n) return bad_arg("cfr_rank_batch: position out of range");
+  return guarded([&]() -> cfr_status { d->d->rank_batch(chars, pos, inclusive, n, out_rank, out_access); return CFR_OK; });
+}
+cfr_status cfr_backward_search_batch(cfr_dev_index *d, const uint8_t *bases, const uint64_t *offsets, const uint32_t *m, size_t n,
+                                     uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep) {
+  if (!d || (n && (!bases || !offsets || !m || !out_l || !out_sp || !out_ep))) return bad_arg("cfr_backward_search_batch: null argument");
+  for (size_t i = 0; i < n; ++i) if (m[i] > offsets[i + 1] - offsets[i]) return bad_arg("cfr_backward_search_batch: m exceeds read length");
+  return guarded([&]() -> cfr_status { d->d->backward_search_batch(bases, offsets, m, n, out_l, out_sp, out_ep); return CFR_OK; });
+}
+cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps) {
+  if (!d || (n && (!rows || !out_val))) return bad_arg("cfr_locate_rows: null argument");
+  for (size_t i = 0; i < n; ++i) if (rows[i] >= d->d->host().n) return bad_arg("cfr_locate_rows: row out of range");
+  return guarded([&]() -> cfr_status { d->d->locate_rows(rows, n, out_val, out_steps); return CFR_OK; });
+}
+
+cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
+                            const uint64_t *offsets2, size_t n, cfr_hit *out_hits, size_t hit_cap, uint64_t *hit_begin) {
+  if (!d || !hit_begin || (n && (!bases1 || !offsets1))) return bad_arg("cfr_search_batch: null argument");
+  if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_search_batch: bases2/offsets2 must both be given");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex::BatchOut out;
+    d->d->run_batch_host(bases1, offsets1, bases2, offsets2, n, false, out);
+    memcpy(hit_begin, out.hit_begin.data(), (n + 1) * 8);
+    if (out.hits.size() > hit_cap) { g_err = "cfr_search_batch: hit buffer too small"; return CFR_ERR_CAPACITY; }
+    if (!out.hits.empty()) memcpy(out_hits, out.hits.data(), out.hits.size() * sizeof(cfr_hit));
+    return CFR_OK;
+  });
+}
+
+static cfr_status finish_classify(cfr_dev_index *d, cfr::DeviceIndex::BatchOut &out, size_t n, cfr_result *results,
+                                  cfr_match *matches, size_t match_cap, size_t *n_matches) {
+  auto t0 = std::chrono::steady_clock::now();
+  std::vector<cfr_match> mv;
+  cfr::classify_batch_tail(d->d->host(), out, n, d->tail_threads, results, mv);
+  d->d->last_stats.tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (n_matches) *n_matches = mv.size();
+  if (mv.size() > match_cap) { g_err = "cfr_classify_batch: match buffer too small"; return CFR_ERR_CAPACITY; }
+  if (!mv.empty()) memcpy(matches, mv.data(), mv.size() * sizeof(cfr_match));
+  return CFR_OK;
+}
+
+cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
+                              const uint64_t *offsets2, size_t n, cfr_result *results, cfr_match *matches, size_t match_cap,
+                              size_t *n_matches) {
+  if (!d || (n && (!bases1 || !offsets1 || !results))) return bad_arg("cfr_classify_batch: null argument");
+  if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch: bases2/offsets2 must both be given");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex::BatchOut out;
+    d->d->run_batch_host(bases1, offsets1, bases2, offsets2, n, true, out);
+    return finish_classify(d, out, n, results, matches, match_cap, n_matches);
+  });
+}
+
+cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1, const void *d_bases2,
+                                       const void *d_offsets2, size_t n, uint64_t total_bases1, uint64_t total_bases2,
+                                       cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches) {
+  if (!d || (n && (!d_bases1 || !d_offsets1 || !results))) return bad_arg("cfr_classify_batch_resident: null argument");
+  if ((d_bases2 == nullptr) != (d_offsets2 == nullptr)) return bad_arg("cfr_classify_batch_resident: mate buffers must both be given");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex::BatchOut out;
+    d->d->run_batch((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
+                    (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, true, out);
+    return finish_classify(d, out, n, results, matches, match_cap, n_matches);
+  });
+}
+
+cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, const uint64_t *hit_begin, const uint64_t *row_begin,
+                                  const uint64_t *row_vals, const int32_t *query_len, size_t n, int threads, cfr_result *results,
+                                  cfr_match *matches, size_t match_cap, size_t *n_matches) {
+  if (!idx || !hit_begin || (n && (!results || !query_len))) return bad_arg("cfr_classify_from_hits: null argument");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex::BatchOut out;
+    out.hit_begin.assign(hit_begin, hit_begin + n + 1);
+    const uint64_t nh = hit_begin[n];
+    out.hits.assign(hits, hits + nh);
+    out.row_begin.assign(row_begin, row_begin + nh + 1);
+    out.row_vals.assign(row_vals, row_vals + row_begin[nh]);
+    out.read_len.assign(query_len, query_len + n);
+    std::vector<cfr_match> mv;
+    cfr::classify_batch_tail(*idx->h, out, n, threads, results, mv);
+    if (n_matches) *n_matches = mv.size();
+    if (mv.size() > match_cap) { g_err = "cfr_classify_from_hits: match buffer too small"; return CFR_ERR_CAPACITY; }
+    if (!mv.empty()) memcpy(matches, mv.data(), mv.size() * sizeof(cfr_match));
+    return CFR_OK;
+  });
+}
+
+cfr_status cfr_last_batch_stats(const cfr_dev_index *d, cfr_batch_stats *st) {
+  if (!d || !st) return bad_arg("cfr_last_batch_stats: null argument");
+  *st = d->d->last_stats;
+  return CFR_OK;
+}
+
+cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads) {
+  if (n && (!bases || !offsets)) return bad_arg("cfr_dust_mask_batch: null argument");
+  if (threads < 1) threads = 1;
+  auto work = [&](int tid) {
+    for (size_t i = (size_t)tid; i < n; i += (size_t)threads) cfr::dust_mask(bases + offsets[i], offsets[i + 1] - offsets[i]);
+  };
+  if (threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  return CFR_OK;
+}
+
+const char *cfr_tsv_header(void) {   // ResultWriter::OutputHeader (ResultWriter.hpp:186-197), no barcode/UMI columns
+  return "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\n";
+}
+
+size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, char *buf, size_t cap) {
+  // ResultWriter::Output (ResultWriter.hpp:209-240)
+  size_t off = 0;
+  auto put = [&](int w) { if (w > 0) off += (size_t)w; };
+  const cfr::Taxonomy &t = idx->h->tax;
+  if (r->n_match > 0) {
+    for (int i = 0; i < r->n_match; ++i) {
+      const cfr_match &m = matches[r->match_begin + (uint64_t)i];
+      const char *name;
+      if (m.kind == 0) name = m.id < t.seq_name.size() ? t.seq_name[m.id].c_str() : "";
+      else name = cfr::tax_rank_string(m.id < t.node_cnt ? t.rank[m.id] : 0);
+      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d\n", read_id,
+                   name, (unsigned long)m.taxid, (unsigned long)r->score, (unsigned long)r->secondary_score, r->hit_length,
+                   r->query_length, r->n_match));
+    }
+  } else {
+    put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\tunclassified\t0\t0\t0\t0\t%d\t1\n", read_id,
+                 r->query_length));
+  }
+  return off;
+}
+
+}  // extern "C"

@@ -1,0 +1,327 @@
+// cfr_device.hip — builds the HBM image of an index and drives the batch pipeline (gfx950 only).
+#include "cfr_device.hpp"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+#include "cfr_kernels.hip.inc"
+
+namespace cfr {
+
+namespace {
+
+inline void hip_check(hipError_t e, const char *what) {
+  if (e != hipSuccess) throw HipError{std::string(what) + ": " + hipGetErrorString(e), (int)e};
+}
+#define HIP_CHECK(x) hip_check((x), #x)
+
+constexpr int kBlock = 256;
+inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
+
+enum Slot : size_t {
+  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
+  S_ROWVALS, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+};
+
+}  // namespace
+
+template <class T> T *DeviceIndex::dev_alloc(size_t count) {
+  void *p = nullptr;
+  size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  HIP_CHECK(hipMalloc(&p, bytes));
+  owned_.push_back(p);
+  device_bytes_ += bytes;
+  return (T *)p;
+}
+
+void *DeviceIndex::scratch(size_t slot, size_t bytes) {
+  if (slots_.size() < S_COUNT) slots_.resize(S_COUNT);
+  Slot &s = slots_[slot];
+  if (s.cap < bytes) {
+    if (s.p) HIP_CHECK(hipFree(s.p));
+    s.p = nullptr;
+    size_t cap = std::max<size_t>(bytes + bytes / 4, 256);
+    HIP_CHECK(hipMalloc(&s.p, cap));
+    s.cap = cap;
+  }
+  return s.p;
+}
+
+DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"no HIP device available (libcfr_hip has no CPU fallback)", -1};
+  if (device < 0 || device >= count) throw HipError{"device ordinal out of range", -1};
+  HIP_CHECK(hipSetDevice(device));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  for (auto &e : ev_) HIP_CHECK(hipEventCreate(&e));
+
+  // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp)
+  const uint64_t nrec = (h.n >> 7) + 2;
+  std::vector<uint64_t> occ(nrec * 8, 0);
+  uint64_t run[4] = {0, 0, 0, 0};   // #c in B[0 .. 64*k)
+  const uint64_t halves = nrec * 2;
+  for (uint64_t k = 0; k < halves; ++k) {
+    // symbols [64k, 64k+64): two packed words of 32 symbols (padding beyond n is symbol 0, counted consistently)
+    uint64_t lo = 0, hi = 0;
+    for (int wq = 0; wq < 2; ++wq) {
+      const uint64_t wi = 2 * k + wq;
+      uint64_t w = wi < h.bwt2.size() ? h.bwt2[wi] : 0;
+      // de-interleave 2-bit symbols into bit planes
+      uint64_t l = w & 0x5555555555555555ull, u = (w >> 1) & 0x5555555555555555ull;
+      auto squeeze = [](uint64_t x) {
+        x = (x | (x >> 1)) & 0x3333333333333333ull;
+        x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+        x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+        x = (x | (x >> 16)) & 0x00000000ffffffffull;
+        return x;
+      };
+      lo |= squeeze(l) << (32 * wq);
+      hi |= squeeze(u) << (32 * wq);
+    }
+    uint64_t *rec = &occ[(k >> 1) * 8];
+    if (k & 1) {
+      // entering the second half: run[] == #c before the midpoint
+      for (int c = 0; c < 4; ++c) rec[c] = run[c];
+    }
+    rec[4 + 2 * (k & 1)] = lo;
+    rec[5 + 2 * (k & 1)] = hi;
+    const uint64_t c3 = (uint64_t)__builtin_popcountll(lo & hi), c2 = (uint64_t)__builtin_popcountll(~lo & hi),
+                   c1 = (uint64_t)__builtin_popcountll(lo & ~hi);
+    run[3] += c3; run[2] += c2; run[1] += c1; run[0] += 64 - c3 - c2 - c1;
+  }
+  for (uint64_t r : h.selected_rows) occ[(r >> 7) * 8] |= kSelFlag;
+  uint64_t *d_occ = dev_alloc<uint64_t>(occ.size());
+  HIP_CHECK(hipMemcpy(d_occ, occ.data(), occ.size() * 8, hipMemcpyHostToDevice));
+  std::vector<uint64_t>().swap(occ);
+
+  uint64_t *d_ftab = dev_alloc<uint64_t>(h.ftab.size());
+  if (!h.ftab.empty()) HIP_CHECK(hipMemcpy(d_ftab, h.ftab.data(), h.ftab.size() * 8, hipMemcpyHostToDevice));
+  uint64_t *d_sampled = dev_alloc<uint64_t>(h.sampled_words.size());
+  HIP_CHECK(hipMemcpy(d_sampled, h.sampled_words.data(), h.sampled_words.size() * 8, hipMemcpyHostToDevice));
+  uint64_t *d_rows = dev_alloc<uint64_t>(h.selected_rows.size());
+  uint64_t *d_vals = dev_alloc<uint64_t>(h.selected_vals.size());
+  if (!h.selected_rows.empty()) {
+    HIP_CHECK(hipMemcpy(d_rows, h.selected_rows.data(), h.selected_rows.size() * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(d_vals, h.selected_vals.data(), h.selected_vals.size() * 8, hipMemcpyHostToDevice));
+  }
+
+  view_.n = h.n;
+  view_.first_isa = h.first_isa;
+  view_.adjusted_sa0 = h.adjusted_sa0;
+  memcpy(view_.C, h.C, sizeof(h.C));
+  view_.occ = d_occ;
+  view_.ftab = d_ftab;
+  view_.sampled = d_sampled;
+  view_.sel_rows = d_rows;
+  view_.sel_vals = d_vals;
+  view_.sel_cnt = h.selected_rows.size();
+  view_.last_code = h.last_code;
+  view_.ftab_width = (uint32_t)h.precompute_width;
+  view_.sampled_bits = (uint32_t)h.sampled_bits;
+  view_.sample_rate = (uint32_t)h.sample_rate;
+  view_.min_hit_len = h.params.min_hit_len;
+  view_.score_adjust = h.score_hit_len_adjust;
+  view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
+  view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
+}
+
+DeviceIndex::~DeviceIndex() {
+  (void)hipSetDevice(device_);
+  for (void *p : owned_) (void)hipFree(p);
+  for (auto &s : slots_) if (s.p) (void)hipFree(s.p);
+  for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+// ------------------------------------------------------------------------------------ probes
+void DeviceIndex::rank_batch(const char *chars, const uint64_t *pos, const uint8_t *incl, size_t n, uint64_t *out_rank, char *out_access) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n == 0) return;
+  char *d_c = (char *)scratch(S_P0, n);
+  uint64_t *d_p = (uint64_t *)scratch(S_P1, n * 8);
+  uint8_t *d_i = (uint8_t *)scratch(S_P2, n);
+  uint64_t *d_r = (uint64_t *)scratch(S_P3, n * 8);
+  char *d_a = (char *)scratch(S_P4, n);
+  HIP_CHECK(hipMemcpyAsync(d_c, chars, n, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_p, pos, n * 8, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_i, incl, n, hipMemcpyHostToDevice, stream_));
+  k_rank_probe<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_c, d_p, d_i, n, d_r, d_a);
+  HIP_CHECK(hipGetLastError());
+  if (out_rank) HIP_CHECK(hipMemcpyAsync(out_rank, d_r, n * 8, hipMemcpyDeviceToHost, stream_));
+  if (out_access) HIP_CHECK(hipMemcpyAsync(out_access, d_a, n, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DeviceIndex::backward_search_batch(const uint8_t *bases, const uint64_t *offsets, const uint32_t *m, size_t n,
+                                        uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n == 0) return;
+  const uint64_t total = offsets[n];
+  uint8_t *d_b = (uint8_t *)scratch(S_IN_B1, total + 16);
+  uint64_t *d_o = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
+  uint32_t *d_m = (uint32_t *)scratch(S_P0, n * 4);
+  uint64_t *d_l = (uint64_t *)scratch(S_P1, n * 8), *d_sp = (uint64_t *)scratch(S_P2, n * 8), *d_ep = (uint64_t *)scratch(S_P3, n * 8);
+  if (total) HIP_CHECK(hipMemcpyAsync(d_b, bases, total, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_o, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_m, m, n * 4, hipMemcpyHostToDevice, stream_));
+  k_bs_probe<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b, d_o, d_m, n, d_l, d_sp, d_ep);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(out_l, d_l, n * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipMemcpyAsync(out_sp, d_sp, n * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipMemcpyAsync(out_ep, d_ep, n * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void DeviceIndex::locate_rows(const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n == 0) return;
+  uint64_t *d_r = (uint64_t *)scratch(S_P0, n * 8), *d_v = (uint64_t *)scratch(S_P1, n * 8);
+  uint32_t *d_s = (uint32_t *)scratch(S_P2, n * 4);
+  HIP_CHECK(hipMemcpyAsync(d_r, rows, n * 8, hipMemcpyHostToDevice, stream_));
+  k_locate<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_r, n, d_v, d_s);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(out_val, d_v, n * 8, hipMemcpyDeviceToHost, stream_));
+  if (out_steps) HIP_CHECK(hipMemcpyAsync(out_steps, d_s, n * 4, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ------------------------------------------------------------------------------------ the path
+namespace {
+void exclusive_scan(void *tmp, size_t tmp_bytes, const uint64_t *in, uint64_t *out, size_t count, hipStream_t st) {
+  // out has count+1 entries; out[count] = total (input padded by the caller with one trailing zero)
+  size_t need = tmp_bytes;
+  HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, (int)(count + 1), st));
+}
+size_t scan_tmp_bytes(size_t count) {
+  size_t need = 0;
+  HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (const uint64_t *)nullptr, (uint64_t *)nullptr, (int)(count + 1)));
+  return need;
+}
+}  // namespace
+
+void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                            uint64_t total1, uint64_t total2, bool want_rows, BatchOut &out) {
+  HIP_CHECK(hipSetDevice(device_));
+  out.hit_begin.assign(n + 1, 0);
+  out.hits.clear();
+  out.row_begin.clear();
+  out.row_vals.clear();
+  out.read_len.assign(n, 0);
+  last_stats = cfr_batch_stats{};
+  if (n == 0) return;
+  const bool paired = d_b2 != nullptr;
+  const int cpr = paired ? 4 : 2;
+  const size_t nchains = n * (size_t)cpr;
+  // capacity bound without a host round trip: sum over chains of (len/(mhl+1) + 1)
+  const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
+  const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
+
+  uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
+  uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
+  cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
+  uint32_t *chain_cnt = (uint32_t *)scratch(S_CHAINCNT, nchains * 4);
+  cfr_hit *fin = (cfr_hit *)scratch(S_FIN, cap_total * sizeof(cfr_hit));
+  uint64_t *fin_cnt = (uint64_t *)scratch(S_FINCNT, (n + 1) * 8);
+  uint64_t *fin_rows = (uint64_t *)scratch(S_FINROWS, cap_total * 8);
+  uint64_t *fin_off = (uint64_t *)scratch(S_FINOFF, (n + 1) * 8);
+  const size_t tmp_bytes = std::max(scan_tmp_bytes(n), scan_tmp_bytes(cap_total));
+  void *tmp = scratch(S_SCAN, tmp_bytes);
+
+  HIP_CHECK(hipEventRecord(ev_[0], stream_));
+  HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
+  k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
+  exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
+  HIP_CHECK(hipEventRecord(ev_[1], stream_));
+  if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
+  else k_search_chains<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(ev_[2], stream_));
+  HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, stream_));
+  if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows);
+  else k_adjust_select<2><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows);
+  HIP_CHECK(hipGetLastError());
+  exclusive_scan(tmp, tmp_bytes, fin_cnt, fin_off, n, stream_);
+  HIP_CHECK(hipEventRecord(ev_[3], stream_));
+  HIP_CHECK(hipMemcpyAsync(out.hit_begin.data(), fin_off, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  const uint64_t nhits = out.hit_begin[n];
+
+  cfr_hit *hits = (cfr_hit *)scratch(S_HITS, (nhits + 1) * sizeof(cfr_hit));
+  uint64_t *rows_per = (uint64_t *)scratch(S_ROWSPER, (nhits + 1) * 8);
+  uint64_t *row_off = (uint64_t *)scratch(S_ROWOFF, (nhits + 1) * 8);
+  k_compact_hits<<<grid_for(n), kBlock, 0, stream_>>>(n, hit_off, fin_off, fin, fin_rows, hits, rows_per);
+  HIP_CHECK(hipGetLastError());
+  out.hits.resize(nhits);
+  if (nhits) HIP_CHECK(hipMemcpyAsync(out.hits.data(), hits, nhits * sizeof(cfr_hit), hipMemcpyDeviceToHost, stream_));
+  uint64_t nrows = 0;
+  HIP_CHECK(hipEventRecord(ev_[4], stream_));
+  HIP_CHECK(hipEventRecord(ev_[5], stream_));
+  if (want_rows) {
+    HIP_CHECK(hipMemsetAsync(rows_per + nhits, 0, 8, stream_));
+    const size_t tmp2 = scan_tmp_bytes(nhits);
+    void *tmpb = scratch(S_SCAN, std::max(tmp_bytes, tmp2));
+    exclusive_scan(tmpb, std::max(tmp_bytes, tmp2), rows_per, row_off, nhits, stream_);
+    out.row_begin.resize(nhits + 1);
+    HIP_CHECK(hipMemcpyAsync(out.row_begin.data(), row_off, (nhits + 1) * 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    nrows = out.row_begin[nhits];
+    uint64_t *rows = (uint64_t *)scratch(S_ROWS, (nrows + 1) * 8);
+    uint64_t *vals = (uint64_t *)scratch(S_ROWVALS, (nrows + 1) * 8);
+    HIP_CHECK(hipEventRecord(ev_[4], stream_));
+    if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, stream_>>>(view_, nhits, hits, row_off, rows);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(ev_[5], stream_));
+    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, stream_>>>(view_, rows, nrows, vals, nullptr);
+    HIP_CHECK(hipGetLastError());
+    out.row_vals.resize(nrows);
+    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    if (nrows) HIP_CHECK(hipMemcpyAsync(out.row_vals.data(), vals, nrows * 8, hipMemcpyDeviceToHost, stream_));
+  } else {
+    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+  }
+  // query lengths (Classifier.hpp:958-960) from the offsets
+  std::vector<uint64_t> o1(n + 1), o2;
+  HIP_CHECK(hipMemcpyAsync(o1.data(), d_o1, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+  if (paired) { o2.resize(n + 1); HIP_CHECK(hipMemcpyAsync(o2.data(), d_o2, (n + 1) * 8, hipMemcpyDeviceToHost, stream_)); }
+  HIP_CHECK(hipEventRecord(ev_[7], stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < n; ++i) {
+    out.read_len[i] = (int32_t)(o1[i + 1] - o1[i]);
+    if (paired) out.read_len[i] += (int32_t)(o2[i + 1] - o2[i]);
+  }
+  auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev_[a], ev_[b]); return t; };
+  last_stats.pack_ms = ms(0, 1);
+  last_stats.search_ms = ms(1, 2);
+  last_stats.adjust_ms = ms(2, 3);
+  last_stats.rows_ms = want_rows ? ms(4, 5) : 0.f;
+  last_stats.locate_ms = want_rows ? ms(5, 6) : 0.f;
+  last_stats.total_ms = ms(0, 7);
+  last_stats.n_chains = nchains;
+  last_stats.n_hits = nhits;
+  last_stats.n_rows = nrows;
+}
+
+void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,
+                                 bool want_rows, BatchOut &out) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n == 0) { run_batch(nullptr, nullptr, nullptr, nullptr, 0, 0, 0, want_rows, out); return; }
+  const uint64_t t1 = o1[n], t2 = b2 ? o2[n] : 0;
+  uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, t1 + 16);
+  uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
+  if (t1) HIP_CHECK(hipMemcpyAsync(d_b1, b1, t1, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  uint8_t *d_b2 = nullptr;
+  uint64_t *d_o2 = nullptr;
+  if (b2) {
+    d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 16);
+    d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
+    if (t2) HIP_CHECK(hipMemcpyAsync(d_b2, b2, t2, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  }
+  run_batch(d_b1, d_o1, d_b2, d_o2, n, t1, t2, want_rows, out);
+}
+
+}  // namespace cfr

@@ -1,0 +1,89 @@
+// cfr_device.hpp — the index image in HBM and the batch pipeline that runs on it (gfx950).
+//
+// Data layout:
+//   occ      : one 64-byte record per 128 BWT symbols
+//                u64 mid[4]   #c in B[0 .. 128*r + 64)      (bit 63 of mid[0]: record holds a selectedSA row)
+//                u64 lo0, hi0 bit planes of symbols   0..63  (bit k of lo = low code bit of symbol k)
+//                u64 lo1, hi1 bit planes of symbols 64..127
+//              => FMIndex::Rank(c, p) / Sequence::Access(p) touch exactly ONE 64-byte record:
+//                 8 B (mid[c]) + 16 B (the half that holds symbol p).
+//   ftab     : (start, count) u64 pairs, 4^w entries          (FMIndex.hpp:27)
+//   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
+//   sel_rows / sel_vals : sorted selectedSA pairs             (FMIndex.hpp:34)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cfr_index.hpp"
+
+namespace cfr {
+
+struct DevView {            // passed by value to kernels
+  uint64_t n, first_isa, adjusted_sa0;
+  uint64_t C[5];
+  const uint64_t *occ;      // 8 u64 per record
+  const uint64_t *ftab;     // 2 u64 per entry
+  const uint64_t *sampled;
+  const uint64_t *sel_rows, *sel_vals;
+  uint64_t sel_cnt;
+  uint32_t last_code, ftab_width, sampled_bits, sample_rate;
+  int32_t min_hit_len, score_adjust;
+  uint64_t max_entries;     // (size_t)(maxResult * maxResultPerHitFactor)
+  int32_t locate_all;       // factor <= 0 || maxResult <= 0
+};
+
+struct HipError { std::string msg; int code; };
+
+class DeviceIndex {
+ public:
+  DeviceIndex(const HostIndex &h, int device);
+  ~DeviceIndex();
+
+  const HostIndex &host() const { return *host_; }
+  int device() const { return device_; }
+  uint64_t device_bytes() const { return device_bytes_; }
+  hipStream_t stream() const { return stream_; }
+
+  void rank_batch(const char *chars, const uint64_t *pos, const uint8_t *incl, size_t n, uint64_t *out_rank, char *out_access);
+  void backward_search_batch(const uint8_t *bases, const uint64_t *offsets, const uint32_t *m, size_t n,
+                             uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep);
+  void locate_rows(const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps);
+
+  // Runs search (+adjust, strand choice) for a batch whose reads are in device memory.
+  // On return the per-read final hits are in host vectors (compacted), plus located seqIds per hit if want_rows.
+  struct BatchOut {
+    std::vector<uint64_t> hit_begin;     // n+1
+    std::vector<cfr_hit> hits;
+    std::vector<uint64_t> row_begin;     // per hit: hits.size()+1 (only when want_rows)
+    std::vector<uint64_t> row_vals;      // located seqIds (only when want_rows)
+    std::vector<int32_t> read_len;       // query length per read (r1 + r2)
+  };
+  void run_batch(const uint8_t *d_bases1, const uint64_t *d_offs1, const uint8_t *d_bases2, const uint64_t *d_offs2,
+                 size_t n, uint64_t total1, uint64_t total2, bool want_rows, BatchOut &out);
+
+  // convenience: host buffers -> device, then run_batch
+  void run_batch_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2,
+                      size_t n, bool want_rows, BatchOut &out);
+
+  cfr_batch_stats last_stats{};
+
+ private:
+  template <class T> T *dev_alloc(size_t count);
+  void *scratch(size_t slot, size_t bytes);
+
+  const HostIndex *host_;
+  int device_;
+  hipStream_t stream_ = nullptr;
+  DevView view_{};
+  std::vector<void *> owned_;
+  uint64_t device_bytes_ = 0;
+  struct Slot { void *p = nullptr; size_t cap = 0; };
+  std::vector<Slot> slots_;
+  hipEvent_t ev_[8] = {};
+};
+
+}  // namespace cfr

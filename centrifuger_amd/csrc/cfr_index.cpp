@@ -1,0 +1,326 @@
+// cfr_index.cpp — .cfr parser (see cfr_index.hpp).  Host C++ only, no HIP.
+#include "cfr_index.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace cfr {
+
+namespace {
+
+// Read-only cursor over an mmap'ed file.
+class Cursor {
+ public:
+  explicit Cursor(const std::string &path) : path_(path) {
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw IoError{"cannot open " + path};
+    struct stat st;
+    if (fstat(fd_, &st) != 0) { ::close(fd_); throw IoError{"cannot stat " + path}; }
+    size_ = (size_t)st.st_size;
+    if (size_ > 0) {
+      base_ = (const uint8_t *)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+      if (base_ == MAP_FAILED) { ::close(fd_); throw IoError{"cannot mmap " + path}; }
+    }
+  }
+  ~Cursor() {
+    if (base_ && size_) munmap((void *)base_, size_);
+    if (fd_ >= 0) ::close(fd_);
+  }
+  template <class T> T get() {
+    T v;
+    need(sizeof(T));
+    memcpy(&v, base_ + pos_, sizeof(T));
+    pos_ += sizeof(T);
+    return v;
+  }
+  void copy(void *dst, size_t bytes) {
+    need(bytes);
+    memcpy(dst, base_ + pos_, bytes);
+    pos_ += bytes;
+  }
+  void skip(size_t bytes) { need(bytes); pos_ += bytes; }
+  bool eof() const { return pos_ >= size_; }
+  size_t remaining() const { return size_ - pos_; }
+
+ private:
+  void need(size_t bytes) const {
+    if (bytes > size_ - pos_) throw FormatError{"truncated file " + path_};
+  }
+  std::string path_;
+  int fd_ = -1;
+  const uint8_t *base_ = nullptr;
+  size_t size_ = 0, pos_ = 0;
+};
+
+inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ALPHABET := u64 space | i32 method | u64 n | [char list[n] | i32 code[256] | i16 codeLen[256]]
+// returns the number of symbols; checks it is the plain 2-bit ACGT coder when non-empty.
+uint64_t parse_alphabet(Cursor &c, bool must_be_acgt) {
+  c.get<uint64_t>();
+  int32_t method = c.get<int32_t>();
+  uint64_t n = c.get<uint64_t>();
+  if (n == 0) return 0;
+  if (n > 255) throw FormatError{"alphabet too large"};
+  char list[256];
+  int32_t code[256];
+  int16_t code_len[256];
+  c.copy(list, n);
+  c.copy(code, sizeof(code));
+  c.copy(code_len, sizeof(code_len));
+  if (must_be_acgt) {
+    bool ok = method == 1 && n == 4 && memcmp(list, "ACGT", 4) == 0;
+    for (int i = 0; ok && i < 4; ++i) ok = code[(unsigned char)list[i]] == i && code_len[(unsigned char)list[i]] == 2;
+    if (!ok) throw FormatError{"only the plain-coded nucleotide alphabet ACGT is supported (protein indexes are out of scope)"};
+  }
+  return n;
+}
+
+// BITVEC := u64 space | u64 n | i32 rb | i32 sb | i32 selectSpeed | i32 selectType | [B | RANK9 | SELECT]
+void parse_bitvector(Cursor &c, RawBitvector &bv) {
+  c.get<uint64_t>();
+  bv.n = c.get<uint64_t>();
+  c.skip(4 * sizeof(int32_t));
+  if (bv.n == 0) return;
+  uint64_t words = ceil_div(bv.n, 64);
+  bv.bits.resize(words);
+  c.copy(bv.bits.data(), words * 8);
+  c.get<uint64_t>();                        // rank9 _space
+  uint64_t word_cnt = c.get<uint64_t>();
+  if (word_cnt != words) throw FormatError{"rank9 word count mismatch"};
+  bv.rank9.resize(2 * ceil_div(word_cnt, 8));
+  c.copy(bv.rank9.data(), bv.rank9.size() * 8);
+  c.get<uint64_t>();                        // select _space
+  uint64_t sel_n = c.get<uint64_t>();
+  int32_t sel_speed = c.get<int32_t>();
+  if (sel_speed != 0 && sel_n != 0) throw FormatError{"bitvector carries select structures (unexpected on this path)"};
+}
+
+// WAVELET := SEQHDR | i32 nodeCnt | i32 selectSpeed | NODE*   ; SEQHDR := u64 space | u64 n | ALPHABET
+void parse_wavelet(Cursor &c, RawWavelet &w) {
+  c.get<uint64_t>();
+  w.n = c.get<uint64_t>();
+  uint64_t asz = parse_alphabet(c, true);
+  int32_t node_cnt = c.get<int32_t>();
+  c.get<int32_t>();
+  if (asz == 0) { w.node_cnt = 0; return; }      // never-initialised tree (--rbbwt-b 1)
+  if (node_cnt != 3) throw FormatError{"wavelet tree with " + std::to_string(node_cnt) + " nodes (expected 3)"};
+  w.node_cnt = 3;
+  for (int i = 0; i < 3; ++i) {
+    c.get<uint64_t>();      // prefix
+    c.get<int32_t>();       // prefixLen
+    w.children[i][0] = c.get<int32_t>();
+    w.children[i][1] = c.get<int32_t>();
+    parse_bitvector(c, w.node[i]);
+  }
+  if (w.children[0][0] < 1 || w.children[0][0] > 2 || w.children[0][1] < 1 || w.children[0][1] > 2 ||
+      w.children[0][0] == w.children[0][1])
+    throw FormatError{"unexpected wavelet tree shape"};
+  if (w.node[0].n != w.n) throw FormatError{"wavelet root length mismatch"};
+}
+
+inline unsigned bit_at(const RawBitvector &bv, uint64_t i) { return (unsigned)((bv.bits[i >> 6] >> (i & 63)) & 1); }
+
+// Sequential reader of a wavelet-coded sequence: no rank needed when symbols are taken in order.
+class WaveletStream {
+ public:
+  explicit WaveletStream(const RawWavelet &w) : w_(w) {}
+  unsigned next() {
+    unsigned hi = bit_at(w_.node[0], pos_++);
+    const RawBitvector &child = w_.node[w_.children[0][hi]];
+    unsigned lo = bit_at(child, child_pos_[hi]++);
+    return (hi << 1) | lo;
+  }
+  uint64_t consumed() const { return pos_; }
+
+ private:
+  const RawWavelet &w_;
+  uint64_t pos_ = 0;
+  uint64_t child_pos_[2] = {0, 0};
+};
+
+void unpack_bwt(HostIndex &h) {
+  h.bwt2.assign(ceil_div(h.n, 32) + 1, 0);
+  WaveletStream plain(h.wavelet_seq), runs(h.run_block_seq);
+  uint64_t pos = 0;
+  auto put = [&](unsigned sym) {
+    h.bwt2[pos >> 5] |= (uint64_t)sym << ((pos & 31) * 2);
+    ++pos;
+  };
+  for (uint64_t bi = 0; bi < h.block_cnt; ++bi) {
+    uint64_t len = h.b;
+    if (pos + len > h.n) len = h.n - pos;
+    if (bit_at(h.use_run_block, bi)) {
+      if (h.run_block_seq.node_cnt == 0) throw FormatError{"run block without a run-block sequence"};
+      unsigned sym = runs.next();
+      for (uint64_t k = 0; k < len; ++k) put(sym);
+    } else {
+      for (uint64_t k = 0; k < len; ++k) put(plain.next());
+    }
+  }
+  if (pos != h.n) throw FormatError{"decoded BWT length mismatch"};
+  if (plain.consumed() != h.wavelet_seq.n || (h.run_block_seq.node_cnt && runs.consumed() != h.run_block_seq.n))
+    throw FormatError{"run-block component lengths do not add up"};
+}
+
+void parse_fm(const std::string &path, HostIndex &h) {
+  Cursor c(path);
+  h.n = c.get<uint64_t>();
+  h.alphabet_bits = c.get<uint64_t>();
+  h.first_isa = c.get<uint64_t>();
+  h.last_chr = c.get<char>();
+  // Sequence_RunBlock
+  c.get<uint64_t>();
+  uint64_t seq_n = c.get<uint64_t>();
+  parse_alphabet(c, true);
+  h.b = c.get<uint64_t>();
+  h.block_cnt = c.get<uint64_t>();
+  if (seq_n != h.n || h.b == 0 || h.block_cnt != ceil_div(h.n, h.b)) throw FormatError{"inconsistent run-block header"};
+  parse_bitvector(c, h.use_run_block);
+  if (h.use_run_block.n != h.block_cnt) throw FormatError{"useRunBlock length mismatch"};
+  parse_wavelet(c, h.wavelet_seq);
+  parse_wavelet(c, h.run_block_seq);
+  // alphabets + C[]
+  parse_alphabet(c, true);
+  uint64_t plain_n = parse_alphabet(c, true);
+  if (plain_n != 4 || h.alphabet_bits != 2) throw FormatError{"unexpected alphabet"};
+  c.copy(h.C, sizeof(h.C));
+  const char *acgt = "ACGT";
+  const char *p = strchr(acgt, h.last_chr);
+  if (!p || !h.last_chr) throw FormatError{"lastChr not in ACGT"};
+  h.last_code = (uint8_t)(p - acgt);
+  // _FMIndexAuxData
+  uint64_t aux_n = c.get<uint64_t>();
+  c.get<int32_t>();                        // sampleStrategy
+  h.sample_rate = c.get<int32_t>();
+  h.sample_size = c.get<uint64_t>();
+  h.precompute_width = c.get<uint64_t>();
+  h.precompute_size = c.get<uint64_t>();
+  h.adjusted_sa0 = c.get<uint64_t>();
+  if (aux_n != h.n || h.sample_rate <= 0) throw FormatError{"inconsistent aux header"};
+  if (h.precompute_width > 15 || h.precompute_size != (h.precompute_width ? (1ull << (2 * h.precompute_width)) : 0))
+    throw FormatError{"unsupported ftab width"};
+  c.get<uint64_t>();                       // FSEA _size (words allocated)
+  h.sampled_bits = c.get<int32_t>();
+  h.sampled_n = c.get<uint64_t>();
+  if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
+  uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
+  h.sampled_words.assign(sw + 2, 0);       // +2: device reads two words unconditionally
+  c.copy(h.sampled_words.data(), sw * 8);
+  h.ftab.resize(2 * h.precompute_size);
+  c.copy(h.ftab.data(), h.ftab.size() * 8);
+  uint64_t max_lcp = c.get<uint64_t>();
+  if (max_lcp > 0) c.skip(2 * ceil_div(h.n, 64) * 8);
+  uint64_t sel_cnt = c.get<uint64_t>();
+  h.selected_filter_rate = c.get<int32_t>();
+  h.selected_rows.resize(sel_cnt);
+  h.selected_vals.resize(sel_cnt);
+  for (uint64_t i = 0; i < sel_cnt; ++i) {
+    h.selected_rows[i] = c.get<uint64_t>();
+    h.selected_vals[i] = c.get<uint64_t>();
+    if (i && h.selected_rows[i] <= h.selected_rows[i - 1]) throw FormatError{"selectedSA rows not ascending"};
+  }
+  h.has_end_marker = false;
+  if (!c.eof()) h.has_end_marker = c.get<uint8_t>() != 0;   // absent in old indexes (FMIndex.hpp:178-181)
+  if (h.has_end_marker) throw FormatError{"end-marker (protein) indexes are out of scope"};
+  unpack_bwt(h);
+}
+
+std::string get_string(Cursor &c) {
+  uint64_t len = c.get<uint64_t>();
+  std::string s(len, '\0');
+  if (len) c.copy(&s[0], len);
+  return s;
+}
+
+// rank enum of Taxonomy.hpp:25-59 and the rank-number table of :94-143
+enum {
+  R_UNKNOWN = 0, R_STRAIN, R_SPECIES, R_GENUS, R_FAMILY, R_ORDER, R_CLASS, R_PHYLUM, R_KINGDOM, R_DOMAIN, R_FORMA,
+  R_INFRA_CLASS, R_INFRA_ORDER, R_PARV_ORDER, R_SUB_CLASS, R_SUB_FAMILY, R_SUB_GENUS, R_SUB_KINGDOM, R_SUB_ORDER,
+  R_SUB_PHYLUM, R_SUB_SPECIES, R_SUB_TRIBE, R_SUPER_CLASS, R_SUPER_FAMILY, R_SUPER_KINGDOM, R_SUPER_ORDER,
+  R_SUPER_PHYLUM, R_TRIBE, R_VARIETAS, R_LIFE, R_ACELLULAR_ROOT, R_MAX
+};
+
+void fill_rank_num(uint8_t *t) {
+  struct { int level; std::vector<int> ranks; } groups[] = {
+      {0, {R_SUB_SPECIES, R_STRAIN}}, {1, {R_SPECIES}}, {2, {R_SUB_GENUS, R_GENUS}},
+      {3, {R_SUB_FAMILY, R_FAMILY, R_SUPER_FAMILY}},
+      {4, {R_SUB_ORDER, R_INFRA_ORDER, R_PARV_ORDER, R_ORDER, R_SUPER_ORDER}},
+      {5, {R_INFRA_CLASS, R_SUB_CLASS, R_CLASS, R_SUPER_CLASS}}, {6, {R_SUB_PHYLUM, R_PHYLUM, R_SUPER_PHYLUM}},
+      {7, {R_SUB_KINGDOM, R_KINGDOM}}, {8, {R_SUPER_KINGDOM, R_ACELLULAR_ROOT, R_DOMAIN}},
+      {9, {R_FORMA, R_SUB_TRIBE, R_TRIBE, R_VARIETAS, R_LIFE, R_UNKNOWN}}};
+  for (auto &g : groups) for (int r : g.ranks) t[r] = (uint8_t)g.level;
+}
+
+void parse_taxonomy(const std::string &path, Taxonomy &t) {
+  Cursor c(path);
+  fill_rank_num(t.rank_num);
+  t.node_cnt = c.get<uint64_t>();
+  t.seq_cnt = c.get<uint64_t>();
+  t.extra_seq_cnt = c.get<uint64_t>();
+  t.parent.resize(t.node_cnt);
+  t.rank.resize(t.node_cnt);
+  for (uint64_t i = 0; i < t.node_cnt; ++i) {   // TaxonomyNode: u64 parent | u8 rank | u8 leaf | u8 pad[6]
+    t.parent[i] = c.get<uint64_t>();
+    t.rank[i] = c.get<uint8_t>();
+    c.skip(7);
+  }
+  uint64_t map_n = c.get<uint64_t>();
+  t.orig_taxid.resize(map_n);
+  c.copy(t.orig_taxid.data(), map_n * 8);
+  t.tax_name.reserve(t.node_cnt);
+  for (uint64_t i = 0; i < t.node_cnt; ++i) t.tax_name.push_back(get_string(c));
+  t.seq_to_tax.resize(t.seq_cnt);
+  c.copy(t.seq_to_tax.data(), t.seq_cnt * 8);
+  uint64_t names = t.seq_cnt + t.extra_seq_cnt;
+  t.seq_name.reserve(names);
+  for (uint64_t i = 0; i < names; ++i) t.seq_name.push_back(get_string(c));
+  t.root = t.node_cnt;
+  for (uint64_t i = 0; i < t.node_cnt; ++i) if (t.parent[i] == i) { t.root = i; break; }
+  if (map_n < t.node_cnt || t.root >= t.node_cnt) throw FormatError{"taxonomy without a root / id map too short"};
+}
+
+bool is_protein(const std::string &prefix) {   // Classifier::IsProteinDatabase (Classifier.hpp:867-895)
+  FILE *fp = fopen((prefix + ".4.cfr").c_str(), "r");
+  if (!fp) return false;
+  char key[128], val[128];
+  bool ret = false;
+  while (fscanf(fp, "%127s %127s", key, val) == 2)
+    if (!strcmp(key, "sequence_type") && !strcmp(val, "amino_acid")) ret = true;
+  fclose(fp);
+  return ret;
+}
+
+}  // namespace
+
+HostIndex *load_index(const std::string &prefix, const cfr_params *params) {
+  if (is_protein(prefix)) throw FormatError{"protein (amino_acid) indexes are out of scope for the MI355X path"};
+  HostIndex *h = new HostIndex();
+  try {
+    parse_fm(prefix + ".1.cfr", *h);
+    parse_taxonomy(prefix + ".2.cfr", h->tax);
+  } catch (...) {
+    delete h;
+    throw;
+  }
+  if (params) h->params = *params; else cfr_params_default(&h->params);
+  if (h->params.min_hit_len <= 0) {
+    // Classifier::InferMinHitLen (Classifier.hpp:113-129): smallest m >= 23 with 4^m / 2 >= 100 n
+    int m = 23;
+    unsigned __int128 space = ((unsigned __int128)1 << (2 * m)) / 2;
+    uint64_t kmerspace = (uint64_t)space;    // 4^23/2 fits in 64 bits
+    for (; m <= 32; ++m) {
+      if (kmerspace >= 100 * h->n) break;
+      kmerspace *= 4;                        // wraps like the reference's uint64_t
+    }
+    h->params.min_hit_len = m;
+  }
+  return h;
+}
+
+}  // namespace cfr

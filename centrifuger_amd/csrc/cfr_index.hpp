@@ -1,0 +1,83 @@
+// cfr_index.hpp — host-side view of a Centrifuger index (<prefix>.1.cfr / .2.cfr / .4.cfr).
+//
+// Clean-room parser of the on-disk format written by the reference's FMIndex::Save
+// (compactds/FMIndex.hpp:571-586), Sequence_RunBlock::Save (Sequence_RunBlock.hpp:468-476),
+// Bitvector_Plain::Save (Bitvector_Plain.hpp:182-196), _FMIndexAuxData::Save (FMIndex.hpp:100-134)
+// and Taxonomy::Save (Taxonomy.hpp:1238-1257); grammar in SURVEY.md Appendix A.
+//
+// The parser keeps the compressed components verbatim (for the run-block device image) and
+// also unpacks the conceptual BWT string into 2-bit symbols (for the flat occurrence image).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/cfr_hip.h"
+
+namespace cfr {
+
+struct RawBitvector {          // Bitvector_Plain + DS_Rank9 as stored
+  uint64_t n = 0;              // bits
+  std::vector<uint64_t> bits;  // ceil(n/64)
+  std::vector<uint64_t> rank9; // 2*ceil(words/8): abs count, 7x9-bit relative counts
+};
+
+struct RawWavelet {            // Sequence_WaveletTree<Bitvector_Plain> for sigma=4: 3 nodes
+  uint64_t n = 0;
+  int node_cnt = 0;
+  int children[3][2] = {{-1, -1}, {-1, -1}, {-1, -1}};
+  RawBitvector node[3];
+};
+
+struct Taxonomy {
+  uint64_t node_cnt = 0, seq_cnt = 0, extra_seq_cnt = 0, root = 0;
+  std::vector<uint64_t> parent;
+  std::vector<uint8_t> rank;
+  std::vector<uint64_t> orig_taxid;
+  std::vector<std::string> tax_name;
+  std::vector<uint64_t> seq_to_tax;
+  std::vector<std::string> seq_name;
+  uint8_t rank_num[64] = {0};   // Taxonomy::_taxRankNum (Taxonomy.hpp:94-143)
+};
+
+struct HostIndex {
+  // FMIndex scalars
+  uint64_t n = 0, alphabet_bits = 0, first_isa = 0;
+  char last_chr = 0;
+  uint8_t last_code = 0;
+  uint64_t C[5] = {0, 0, 0, 0, 0};
+  // run-block components
+  uint64_t b = 0, block_cnt = 0;
+  RawBitvector use_run_block;
+  RawWavelet wavelet_seq, run_block_seq;
+  // aux
+  int32_t sample_rate = 0;
+  uint64_t sample_size = 0, precompute_width = 0, precompute_size = 0, adjusted_sa0 = 0;
+  int32_t sampled_bits = 0;
+  uint64_t sampled_n = 0;
+  std::vector<uint64_t> sampled_words;
+  std::vector<uint64_t> ftab;           // pairs (start, count)
+  int32_t selected_filter_rate = 1024;
+  std::vector<uint64_t> selected_rows, selected_vals;   // ascending rows
+  bool has_end_marker = false;
+  // conceptual BWT, 2 bits per symbol, 32 symbols per word, symbol i at bits [2*(i%32), +2)
+  std::vector<uint64_t> bwt2;
+  // taxonomy + parameters
+  Taxonomy tax;
+  cfr_params params;
+  int score_hit_len_adjust = 15;   // Classifier.hpp:848
+};
+
+// Throws std::runtime_error with a message; cfr_capi.cpp maps it to cfr_status.
+struct FormatError { std::string msg; };
+struct IoError { std::string msg; };
+
+HostIndex *load_index(const std::string &prefix, const cfr_params *params);
+
+// reference 2-bit symbol at BWT position i
+inline unsigned bwt_symbol(const HostIndex &h, uint64_t i) {
+  return (unsigned)((h.bwt2[i >> 5] >> ((i & 31) * 2)) & 3);
+}
+
+}  // namespace cfr

@@ -1,0 +1,178 @@
+/*
+ * cfr_hip.h — C-ABI of libcfr_hip.so: the MI355X (gfx950) replacement for Centrifuger's
+ * per-read classification hot path.
+ *
+ * The reference has no FFI layer; the seam this library replaces is the per-batch thread
+ * fan-out around Classifier<Sequence_RunBlock>::Query:
+ *
+ *   reference                                                   this library
+ *   ---------------------------------------------------------   ---------------------------
+ *   Classifier::Init(idxPrefix, param)   Classifier.hpp:902-947  cfr_index_open + cfr_device_index_create
+ *   FMIndex::Load / Taxonomy::Load       FMIndex.hpp:588-606,    (inside cfr_index_open)
+ *                                        Taxonomy.hpp:1259-1287
+ *   pthread_create(ClassifyReads_Thread) CentrifugerClass.cpp:   cfr_classify_batch
+ *     ... Query(r1, r2, result) ...        681-688, 240-340,
+ *                                          Classifier.hpp:950-961
+ *   SearchForwardAndReverse              Classifier.hpp:509-583  cfr_search_batch  (device)
+ *   FMIndex::BackwardToSampledSA         FMIndex.hpp:514-524     cfr_locate_rows   (device)
+ *   FMIndex::Rank / Sequence::Access     FMIndex.hpp:352-362,    cfr_rank_batch    (device; parity probe of
+ *                                        Sequence.hpp:44-55                          the "operator API" of the path)
+ *   FMIndex::BackwardSearch              FMIndex.hpp:487-510     cfr_backward_search_batch (device probe)
+ *   ResultWriter::Output                 ResultWriter.hpp:199-242 cfr_format_tsv
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host buffer; the library
+ * owns device memory.  Every call returns a cfr_status; cfr_last_error() gives the message of
+ * the last failing call on this thread.  The library never calls exit().  There is NO CPU
+ * fallback: without a usable HIP device cfr_device_index_create fails with CFR_ERR_NO_DEVICE.
+ *
+ * Reads are passed as one flat ASCII buffer plus n+1 byte offsets (no terminators), already
+ * dust-masked if the caller wants dust (the reference masks before Query,
+ * CentrifugerClass.cpp:276-316; cfr_dust_mask_batch does the same on the host).
+ */
+#ifndef CFR_HIP_H
+#define CFR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int cfr_status;
+enum {
+  CFR_OK = 0,
+  CFR_ERR_IO = 1,          /* cannot open / short read */
+  CFR_ERR_FORMAT = 2,      /* malformed or unsupported .cfr content (e.g. protein index) */
+  CFR_ERR_NO_DEVICE = 3,   /* no HIP device / HIP runtime error at setup */
+  CFR_ERR_HIP = 4,         /* HIP runtime error during a batch */
+  CFR_ERR_ARG = 5,         /* bad argument */
+  CFR_ERR_CAPACITY = 6     /* caller-provided output buffer too small */
+};
+
+typedef struct cfr_index cfr_index;           /* host copy of <prefix>.{1,2,4}.cfr */
+typedef struct cfr_dev_index cfr_dev_index;   /* flat image of the index in one GPU's HBM */
+
+/* _classifierParam (Classifier.hpp:17-38) */
+typedef struct {
+  int32_t max_result;               /* -k, default 1 */
+  int32_t min_hit_len;              /* --min-hitlen, <=0: infer (Classifier.hpp:113-129) */
+  int32_t max_result_per_hit_factor;/* --hitk-factor, default 40 */
+  int32_t reserved;
+  uint64_t consider_secondary_hit_len;     /* 2000 */
+  double consider_secondary_score_factor;  /* 0.995 */
+} cfr_params;
+
+/* _BWTHit (Classifier.hpp:70-85) */
+typedef struct {
+  uint64_t sp, ep;
+  int32_t l, strand, offset, pad;
+} cfr_hit;
+
+/* _classifierResult (Classifier.hpp:41-59) as POD.  Matches live in a separate array:
+ * read i owns matches [match_begin, match_begin + n_match). */
+typedef struct {
+  uint64_t score, secondary_score;
+  int32_t hit_length, query_length;
+  int32_t n_match;            /* 0 = unclassified */
+  int32_t pad;
+  uint64_t match_begin;
+} cfr_result;
+
+typedef struct {
+  uint64_t id;       /* kind 0: seqId (name = sequence name); kind 1: compact tax id (name = rank string) */
+  uint64_t taxid;    /* ORIGINAL tax id (column 3 of the TSV) */
+  int32_t kind, pad;
+} cfr_match;
+
+/* index geometry, for tests and sizing */
+typedef struct {
+  uint64_t n;                  /* BWT length */
+  uint64_t first_isa;
+  uint64_t block_size;         /* run-block b (== n when built with --rbbwt-b 1) */
+  uint64_t precompute_width;   /* ftab chars */
+  uint64_t sample_rate;
+  uint64_t selected_cnt;
+  uint64_t seq_cnt, node_cnt;
+  int32_t min_hit_len;         /* after inference */
+  char last_chr;
+  char pad[3];
+  uint64_t device_bytes;       /* 0 for a host index */
+} cfr_index_info;
+
+/* kernel timing of the last batch call on a device index (HIP events on the library's stream) */
+typedef struct {
+  float pack_ms, search_ms, adjust_ms, rows_ms, locate_ms, tail_ms, total_ms;
+  uint64_t n_chains, n_hits, n_rows;
+} cfr_batch_stats;
+
+void cfr_params_default(cfr_params *p);
+const char *cfr_last_error(void);
+const char *cfr_version(void);
+
+/* ---- index lifetime ---- */
+cfr_status cfr_index_open(const char *idx_prefix, const cfr_params *params, cfr_index **out);
+void cfr_index_destroy(cfr_index *idx);
+cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info);
+
+cfr_status cfr_device_count(int *count);
+cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out);
+void cfr_device_index_destroy(cfr_dev_index *d);
+cfr_status cfr_device_index_get_info(const cfr_dev_index *d, cfr_index_info *info);
+
+/* ---- primitive probes (device): used by the parity tests of L0-L2 ---- */
+/* FMIndex::Rank(c, pos, inclusive) and Sequence::Access(pos) for n queries.
+ * chars[i] in "ACGT"; out_rank may be NULL, out_access may be NULL. */
+cfr_status cfr_rank_batch(cfr_dev_index *d, const char *chars, const uint64_t *pos, const uint8_t *inclusive,
+                          size_t n, uint64_t *out_rank, char *out_access);
+/* FMIndex::BackwardSearch(s = read[0..m), m): out_l / out_sp / out_ep (sp,ep untouched -> value 0 when l==0 path) */
+cfr_status cfr_backward_search_batch(cfr_dev_index *d, const uint8_t *bases, const uint64_t *offsets,
+                                     const uint32_t *m, size_t n, uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep);
+/* FMIndex::BackwardToSampledSA(row): value (a sequence id) and LF-step count */
+cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps);
+
+/* ---- the path ---- */
+/* SearchForwardAndReverse for n reads (mates optional: bases2/offsets2 == NULL for single-end).
+ * hits of read i are out_hits[hit_begin[i] .. hit_begin[i+1]) ; hit_begin has n+1 entries.
+ * out_hits capacity in elements = hit_cap ; CFR_ERR_CAPACITY if too small (needed size in hit_begin[n]). */
+cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
+                            const uint8_t *bases2, const uint64_t *offsets2, size_t n,
+                            cfr_hit *out_hits, size_t hit_cap, uint64_t *hit_begin);
+
+/* Query for n reads: search + locate on the device, scoring / taxonomy tail, POD results.
+ * results: n entries.  matches: capacity match_cap entries, *n_matches = entries used.
+ * host buffers in, host buffers out. */
+cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
+                              const uint8_t *bases2, const uint64_t *offsets2, size_t n,
+                              cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
+
+/* Same, with the read buffers ALREADY RESIDENT in this device's HBM (device pointers).
+ * This is the entry bench.py times (inputs resident, results returned to host memory). */
+cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1,
+                                       const void *d_bases2, const void *d_offsets2, size_t n,
+                                       uint64_t total_bases1, uint64_t total_bases2,
+                                       cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
+
+cfr_status cfr_last_batch_stats(const cfr_dev_index *d, cfr_batch_stats *st);
+
+/* Host-only tail of Query: GetClassificationFromHits (Classifier.hpp:585-843) once the device has
+ * produced the hits and the located sequence ids.  hits of read i: [hit_begin[i], hit_begin[i+1]);
+ * located ids of hit h: row_vals[row_begin[h] .. row_begin[h+1]).  query_len[i] = strlen(r1)+strlen(r2). */
+cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, const uint64_t *hit_begin,
+                                  const uint64_t *row_begin, const uint64_t *row_vals, const int32_t *query_len,
+                                  size_t n, int threads, cfr_result *results, cfr_match *matches, size_t match_cap,
+                                  size_t *n_matches);
+
+/* ---- host helpers around the path ---- */
+/* SDUST pre-step (Dustmasker.hpp:357-421 + CentrifugerClass.cpp:283-289): masked bases -> 'N', in place */
+cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads);
+
+/* ResultWriter::Output rows for one read (ResultWriter.hpp:209-240).  Returns bytes needed; writes at most cap. */
+size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches,
+                      char *buf, size_t cap);
+const char *cfr_tsv_header(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFR_HIP_H */

@@ -1,0 +1,163 @@
+"""CPU-side checks of the product's host code: the C-ABI surface, the .cfr parser, SDUST, the host
+tail (fed with hits / located ids produced by the oracle), TSV formatting.  No GPU needed."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as ora
+from centrifuger_amd import capi
+from conftest import GOLDEN, ROOT
+
+MAN = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "cfr_hip.h")).read()
+    declared = set(re.findall(r"\b(cfr_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = capi.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/cfr_hip.h but not exported"
+    assert declared == set(capi.EXPORTS)
+
+
+def test_struct_layouts_match_header():
+    assert capi.HIT_DTYPE.itemsize == 32 and capi.RESULT_DTYPE.itemsize == 40 and capi.MATCH_DTYPE.itemsize == 24
+    assert C.sizeof(capi.Params) == 32
+
+
+@pytest.mark.parametrize("iname", ["f6", "f6_b1", "f6_b8", "f6_off3", "f10"])
+def test_parser_reads_every_index_variant(iname, golden_dir):
+    idx = capi.Index(os.path.join(golden_dir, iname))
+    info = idx.info()
+    assert info.n == 300000 and info.min_hit_len == 23
+    assert info.precompute_width == (10 if iname == "f10" else 6)
+    assert info.sample_rate == (8 if iname == "f6_off3" else 16)
+    if iname == "f6_b1":
+        assert info.block_size == info.n
+    if iname == "f6_b8":
+        assert info.block_size == 8
+    assert info.seq_cnt == 15 and info.selected_cnt == 14
+
+
+def test_open_errors_are_statuses_not_exits(tmp_path):
+    with pytest.raises(capi.CfrError) as e:
+        capi.Index(str(tmp_path / "nope"))
+    assert e.value.status == capi.CFR_ERR_IO
+    bad = tmp_path / "bad"
+    (tmp_path / "bad.1.cfr").write_bytes(b"\x01" * 100)
+    (tmp_path / "bad.2.cfr").write_bytes(b"\x01" * 100)
+    with pytest.raises(capi.CfrError) as e:
+        capi.Index(str(bad))
+    assert e.value.status == capi.CFR_ERR_FORMAT
+    prot = tmp_path / "prot"
+    (tmp_path / "prot.4.cfr").write_text("version\t1\nsequence_type\tamino_acid\n")
+    with pytest.raises(capi.CfrError) as e:
+        capi.Index(str(prot))
+    assert e.value.status == capi.CFR_ERR_FORMAT
+
+
+def test_no_device_is_a_loud_error_not_a_fallback(golden_dir):
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    idx = capi.Index(os.path.join(golden_dir, "f6"))
+    with pytest.raises(capi.CfrError) as e:
+        capi.DeviceIndex(idx)
+    assert e.value.status == capi.CFR_ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("fname", ["se.fq", "edge.fa", "long.fq"])
+def test_dust_matches_oracle(fname, golden_dir):
+    ids, bases, offs = ora.read_fastx(os.path.join(golden_dir, fname))
+    masked = capi.dust_mask(bases.copy(), offs, threads=3)
+    changed = 0
+    for i in range(len(ids)):
+        s = bases[int(offs[i]):int(offs[i + 1])].tobytes()
+        want = ora.dust_mask(s)
+        got = masked[int(offs[i]):int(offs[i + 1])].tobytes()
+        assert got == want, ids[i]
+        changed += got != s
+    if fname == "edge.fa":
+        assert changed >= 3     # polyA, dinuc, lowcomplex_mid
+
+
+def test_dust_random_low_complexity():
+    rng = np.random.default_rng(5)
+    seqs = []
+    for _ in range(300):
+        L = int(rng.integers(1, 400))
+        unit = bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(1, 6))).tolist())
+        s = bytearray(rng.choice(list(b"ACGT"), size=L).tolist())
+        a = int(rng.integers(0, L)); b = int(rng.integers(a, L))
+        s[a:b] = (unit * (L // len(unit) + 1))[: b - a]
+        seqs.append(bytes(s))
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64); offs[1:] = np.cumsum([len(s) for s in seqs])
+    bases = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    masked = capi.dust_mask(bases, offs)
+    for i, s in enumerate(seqs):
+        assert masked[int(offs[i]):int(offs[i + 1])].tobytes() == ora.dust_mask(s)
+
+
+def _rows_for_hit(h, max_entries, locate_all, min_hit_len):
+    """the row sequence of Classifier.hpp:620-666"""
+    if h["l"] < min_hit_len:
+        return []
+    sp, ep = int(h["sp"]), int(h["ep"])
+    rng = ep - sp + 1
+    if rng <= max_entries or locate_all:
+        return list(range(sp, ep + 1))
+    step = -(-rng // max_entries)
+    rows = list(range(sp, ep + 1, step))
+    resolved = len(rows)
+    j = ep
+    while sp <= j <= ep:
+        rows.append(j); resolved += 1
+        if resolved >= max_entries:
+            break
+        j -= step
+    return rows
+
+
+@pytest.mark.parametrize("case", ["f6.se_default", "f6.pe_k5", "f6.se_hitk2", "f6.edge_pe_k3", "f6.long_default", "f10.se_k5"])
+def test_host_tail_from_oracle_hits_reproduces_reference_tsv(case, golden_dir):
+    c = MAN["cases"][case]
+    args = c["args"]
+    kw = {}
+    if "-k" in args: kw["max_result"] = int(args[args.index("-k") + 1])
+    if "--hitk-factor" in args: kw["hitk_factor"] = int(args[args.index("--hitk-factor") + 1])
+    if "--min-hitlen" in args: kw["min_hit_len"] = int(args[args.index("--min-hitlen") + 1])
+    prefix = os.path.join(golden_dir, c["index"])
+    o = ora.OracleIndex(prefix, **kw)
+    params = capi.default_params(max_result=kw.get("max_result", 1), max_result_per_hit_factor=kw.get("hitk_factor", 40),
+                                 min_hit_len=kw.get("min_hit_len", 0))
+    idx = capi.Index(prefix, params)
+    mhl = idx.info().min_hit_len
+    if "-u" in args:
+        ids, b1, o1 = ora.read_fastx(os.path.join(golden_dir, args[args.index("-u") + 1])); b2 = o2 = None
+    else:
+        ids, b1, o1 = ora.read_fastx(os.path.join(golden_dir, args[args.index("-1") + 1]))
+        _, b2, o2 = ora.read_fastx(os.path.join(golden_dir, args[args.index("-2") + 1]))
+    if "--no-dust" not in args:
+        capi.dust_mask(b1, o1)
+        if b2 is not None: capi.dust_mask(b2, o2)
+    max_entries = params.max_result * params.max_result_per_hit_factor
+    locate_all = params.max_result_per_hit_factor <= 0 or params.max_result <= 0
+    hits, hit_begin, row_begin, row_vals, qlen = [], [0], [0], [], []
+    for i in range(len(ids)):
+        r1 = b1[int(o1[i]):int(o1[i + 1])].tobytes()
+        r2 = None if b2 is None else b2[int(o2[i]):int(o2[i + 1])].tobytes()
+        for h in o.query_hits(r1, r2):
+            hits.append((h["sp"], h["ep"], h["l"], h["strand"], h["offset"], 0))
+            rows = _rows_for_hit(h, max_entries % (1 << 64), locate_all, mhl)
+            row_vals.extend(o.locate(r)[0] for r in rows)
+            row_begin.append(len(row_vals))
+        hit_begin.append(len(hits))
+        qlen.append(len(r1) + (len(r2) if r2 is not None else 0))
+    results, matches = idx.classify_from_hits(np.array(hits, dtype=capi.HIT_DTYPE), hit_begin, row_begin,
+                                              np.array(row_vals, dtype=np.uint64), qlen, threads=3)
+    out = capi.tsv_header() + b"".join(idx.format_tsv(ids[i], results[i], matches) for i in range(len(ids)))
+    assert out == open(os.path.join(GOLDEN, "tsv", case + ".tsv"), "rb").read()
