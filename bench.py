@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py — classified reads/s of the MI355X hot path (BASELINE.json metric).
+
+A "step" = one pass of the hot path (Classifier::Query for every read: search + locate on the
+device, scoring/taxonomy tail) over one batch of synthetic reads that are ALREADY RESIDENT in HBM.
+Workload at N=1 = BASELINE.json configs[1]: ~1 Gbp synthetic bacterial index (250 genomes x 4 Mbp,
+50 species x 5 strains), 10 M synthetic 150 bp single-end reads, default options (-k 1).
+N>1: one process per GPU, index replicated, each rank classifies its own 10 M reads (weak scaling,
+no data-path collective); value = all reads / max-over-ranks time.
+
+Also reported on the same JSON line:
+  roofline     — dominant kernel (k_search_chains): algorithmic bytes (counted exactly by
+                 the C oracle on a sample and scaled per read) / kernel time from HIP events inside the library.
+  cpu_baseline — the REAL reference binary (oracle/_ref/centrifuger, compiled from /root/reference in the dev
+                 container) on this box's host cores, on a bounded sample of the same reads, and a byte-level
+                 TSV parity check GPU vs reference on that sample.
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def build_index(args, cache):
+    """Index generation is OUT of the timed path.  Uses the reference's own centrifuger-build (oracle/_ref)."""
+    from centrifuger_amd import synth
+    prefix = os.path.join(cache, "idx")
+    if os.path.exists(prefix + ".done"):
+        return prefix
+    os.makedirs(cache, exist_ok=True)
+    t0 = time.time()
+    g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed)
+    synth.write_reference_inputs(g, cache)
+    np.save(os.path.join(cache, "genome_cat.npy"), np.concatenate(g.seqs))
+    np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum([len(s) for s in g.seqs])]).astype(np.int64))
+    log(f"genomes: {g.total_len/1e6:.0f} Mbp generated+written in {time.time()-t0:.1f}s")
+    t0 = time.time()
+    builder = os.path.join(ROOT, "oracle", "_ref", "centrifuger-build")
+    if not os.path.exists(builder):
+        raise SystemExit("oracle/_ref/centrifuger-build missing: run __graft_entry__.build() where /root/reference exists")
+    subprocess.run([builder, "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "ref.fa"),
+                    "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
+                    "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    log(f"index built by reference centrifuger-build in {time.time()-t0:.1f}s")
+    os.remove(os.path.join(cache, "ref.fa"))
+    open(prefix + ".done", "w").close()
+    return prefix
+
+
+def make_reads_gpu(torch, cat_d, starts, n_reads, read_len, seed, device, sub_rate=0.01, n_rate=0.001):
+    """Synthetic reads generated directly in HBM (uniform over genomes/positions/strands, 1 % subs, 0.1 % N)."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    starts_d = torch.as_tensor(starts, device=device)
+    lens = starts_d[1:] - starts_d[:-1]
+    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for i, a in enumerate(b"ACGT"):
+        code[a] = i
+    ar = torch.arange(read_len, device=device)
+    chunk = 1 << 20
+    for lo in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - lo)
+        gi = torch.randint(0, len(lens), (m,), generator=gen, device=device)
+        pos = (torch.rand(m, generator=gen, device=device, dtype=torch.float64) * (lens[gi] - read_len).double()).long()
+        r = cat_d[(starts_d[gi] + pos)[:, None] + ar[None, :]]
+        rc = torch.rand(m, generator=gen, device=device) < 0.5
+        r = torch.where(rc[:, None], comp[r.long()].flip(1), r)
+        sub = torch.rand((m, read_len), generator=gen, device=device) < sub_rate
+        shift = torch.randint(1, 4, (m, read_len), generator=gen, device=device)
+        r = torch.where(sub, acgt[(code[r.long()] + shift) & 3], r)
+        isn = torch.rand((m, read_len), generator=gen, device=device) < n_rate
+        r = torch.where(isn, torch.full_like(r, ord("N")), r)
+        out[lo:lo + m] = r
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--species", type=int, default=50)
+    ap.add_argument("--strains", type=int, default=5)
+    ap.add_argument("--genome-len", type=int, default=4_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=20260928)
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads given to the CPU reference baseline")
+    ap.add_argument("--count-sample", type=int, default=200_000, help="reads the C oracle counts operations on")
+    ap.add_argument("--build-threads", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from centrifuger_amd import capi
+    key = hashlib.md5(f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}".encode()).hexdigest()[:10]
+    cache = os.path.join(args.cache, key)
+    if rank == 0:
+        prefix = build_index(args, cache)
+    if dist is not None:
+        dist.barrier()
+    prefix = os.path.join(cache, "idx")
+
+    t0 = time.time()
+    idx = capi.Index(prefix)
+    dev = capi.DeviceIndex(idx, local_rank)
+    info = dev.info()
+    log(f"rank {rank}: index n={info.n} b={info.block_size} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
+
+    cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
+    starts = np.load(os.path.join(cache, "genome_starts.npy"))
+    cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
+    reads_d = make_reads_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
+    del cat_d
+    offs_d = (torch.arange(args.reads + 1, device=device, dtype=torch.int64) * args.read_len)
+    torch.cuda.synchronize()
+    total_bases = args.reads * args.read_len
+    results = np.zeros(args.reads, dtype=capi.RESULT_DTYPE)
+    matches = np.zeros(2 * args.reads + 16, dtype=capi.MATCH_DTYPE)
+
+    def step():
+        return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, results=results, matches=matches)
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kstats = []
+    for _ in range(args.steps):
+        step()
+        kstats.append(dev.last_stats())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    classified = int((results["n_match"] > 0).sum())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    total_reads = args.reads * args.steps * world
+    value = total_reads / elapsed
+    search_ms = float(np.mean([s.search_ms for s in kstats]))
+    out = {
+        "metric": "classified reads/sec (150 bp)", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), "
+                               f"{args.reads} x {args.read_len} bp SE reads per step per GPU, -k 1, inputs resident in HBM",
+                   "index_bp": int(info.n), "reads_per_step_per_gpu": args.reads, "read_len": args.read_len,
+                   "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective"},
+        "classified_fraction": classified / args.reads,
+        "stage_ms": {k: float(np.mean([getattr(s, k) for s in kstats])) for k in
+                     ("pack_ms", "search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")},
+    }
+
+    # ---- roofline of the dominant kernel: algorithmic bytes counted by the C oracle on a sample
+    import oracle_lib as ora
+    ns = min(args.count_sample, args.reads)
+    sample = reads_d[:ns].cpu().numpy().reshape(-1)
+    soffs = (np.arange(ns + 1, dtype=np.uint64) * np.uint64(args.read_len))
+    o = ora.OracleIndex(prefix)
+    threads = min(os.cpu_count() or 1, 64)
+    ores, cnt = o.classify(sample, soffs, threads=threads, counters=True)
+    c = cnt.as_dict()
+    # bytes of the search kernel = everything except the locate part (sampled/filter reads and the LF-walk ranks);
+    # the LF walk costs per step 1 Access + 1 Rank on the run-block structure: count it separately
+    bytes_all = cnt.algorithmic_bytes() / ns
+    out["roofline"] = {
+        "bound": "hbm", "kernel": "k_search_chains",
+        "achieved": bytes_all * args.reads / (search_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": bytes_all * args.reads / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+        "algorithmic_bytes_per_read": bytes_all, "kernel_ms": search_ms,
+        "ops_per_read": {k: v / ns for k, v in c.items()},
+    }
+
+    # ---- CPU baseline: the real reference binary on this box's host cores + TSV parity on the sample
+    refbin = os.path.join(ROOT, "oracle", "_ref", "centrifuger")
+    if not args.no_cpu_baseline and os.path.exists(refbin):
+        from centrifuger_amd import synth
+        ncpu = os.cpu_count() or 1
+        nb = min(args.cpu_sample, args.reads)
+        rs = synth.ReadSet(reads_d[:nb].cpu().numpy().reshape(-1), (np.arange(nb + 1, dtype=np.uint64) * np.uint64(args.read_len)))
+        fa = os.path.join(cache, f"sample_{rank}.fa")
+        synth.write_fasta(rs, fa)
+        one = os.path.join(cache, "one.fa")
+        synth.write_fasta(rs.slice(0, 1), one)
+        t0 = time.time()
+        subprocess.run([refbin, "-x", prefix, "-u", one, "-t", str(ncpu)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        t_load = time.time() - t0
+        t0 = time.time()
+        ref_tsv = subprocess.run([refbin, "-x", prefix, "-u", fa, "-t", str(ncpu)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        t_full = time.time() - t0
+        cpu_rate = nb / max(t_full - t_load, 1e-9)
+        # GPU TSV on the same sample (dust applied on the host exactly like the reference does)
+        b = rs.bases.copy()
+        capi.dust_mask(b, rs.offsets, threads=min(ncpu, 64))
+        r2, m2 = dev.classify(b, rs.offsets)
+        gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
+        out["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": ncpu, "kind": "reference",
+                               "sample": f"first {nb} reads of the step batch, oracle/_ref/centrifuger -t {ncpu}, "
+                                         f"wall {t_full:.1f}s minus index-load run {t_load:.1f}s (end-to-end incl. FASTA parse, dust, TSV)"}
+        out["parity"] = {"reads": nb, "tsv_identical_to_reference": gpu_tsv == ref_tsv,
+                         "md5": hashlib.md5(gpu_tsv).hexdigest()}
+        out["speedup_vs_cpu"] = value / world / cpu_rate
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
