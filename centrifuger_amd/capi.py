@@ -50,7 +50,7 @@ EXPORTS = [
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_destroy", "cfr_device_index_get_info",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
-    "cfr_format_tsv", "cfr_tsv_header",
+    "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
 ]
 
 _lib = None
@@ -66,9 +66,12 @@ def lib():
         L.cfr_version.restype = C.c_char_p
         L.cfr_tsv_header.restype = C.c_char_p
         L.cfr_format_tsv.restype = C.c_size_t
+        L.cfr_host_alloc.restype = C.c_void_p
+        L.cfr_host_alloc.argtypes = [C.c_size_t]
+        L.cfr_host_free.argtypes = [C.c_void_p]
         for name in EXPORTS:
             if name not in ("cfr_last_error", "cfr_version", "cfr_tsv_header", "cfr_format_tsv", "cfr_index_destroy",
-                            "cfr_device_index_destroy", "cfr_params_default"):
+                            "cfr_device_index_destroy", "cfr_params_default", "cfr_host_alloc", "cfr_host_free"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -221,7 +224,7 @@ class DeviceIndex:
         bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
         n = len(offsets1) - 1
         results = np.zeros(n, dtype=RESULT_DTYPE)
-        cap = max(16, 2 * n)
+        cap = max(16, max(1, self.index.params.max_result) * n)
         while True:
             matches = np.zeros(cap, dtype=MATCH_DTYPE)
             nm = C.c_size_t(0)
@@ -239,7 +242,7 @@ class DeviceIndex:
         if results is None:
             results = np.zeros(n, dtype=RESULT_DTYPE)
         if matches is None:
-            matches = np.zeros(max(16, 2 * n), dtype=MATCH_DTYPE)
+            matches = np.zeros(max(16, max(1, self.index.params.max_result) * n), dtype=MATCH_DTYPE)
         nm = C.c_size_t(0)
         st = lib().cfr_classify_batch_resident(self._d, C.c_void_p(d_bases1), C.c_void_p(d_offsets1),
                                                C.c_void_p(d_bases2 or None), C.c_void_p(d_offsets2 or None), C.c_size_t(n),
@@ -270,3 +273,22 @@ def dust_mask(bases, offsets, threads=1):
 
 def tsv_header() -> bytes:
     return lib().cfr_tsv_header()
+
+
+class PinnedArray:
+    """numpy view over cfr_host_alloc memory (pinned: D2H lands at PCIe rate)."""
+
+    def __init__(self, count: int, dtype):
+        self.dtype = np.dtype(dtype)
+        self.nbytes = max(16, count * self.dtype.itemsize)
+        self._p = lib().cfr_host_alloc(C.c_size_t(self.nbytes))
+        if not self._p:
+            raise CfrError(-1, "cfr_host_alloc failed")
+        buf = (C.c_uint8 * self.nbytes).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=count)
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().cfr_host_free(C.c_void_p(self._p))
+            self._p = None

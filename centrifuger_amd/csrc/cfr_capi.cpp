@@ -1,5 +1,4 @@
 // cfr_capi.cpp — the extern "C" surface declared in include/cfr_hip.h.
-#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -21,6 +20,8 @@ template <class F> cfr_status guarded(F &&f) {
     g_err = e.msg; return CFR_ERR_IO;
   } catch (const cfr::FormatError &e) {
     g_err = e.msg; return CFR_ERR_FORMAT;
+  } catch (const cfr::CapacityError &e) {
+    g_err = e.msg; return CFR_ERR_CAPACITY;
   } catch (const cfr::HipError &e) {
     g_err = e.msg; return e.code == -1 ? CFR_ERR_NO_DEVICE : CFR_ERR_HIP;
   } catch (const std::exception &e) {
@@ -122,27 +123,14 @@ cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint6
   });
 }
 
-static cfr_status finish_classify(cfr_dev_index *d, cfr::DeviceIndex::BatchOut &out, size_t n, cfr_result *results,
-                                  cfr_match *matches, size_t match_cap, size_t *n_matches) {
-  auto t0 = std::chrono::steady_clock::now();
-  std::vector<cfr_match> mv;
-  cfr::classify_batch_tail(d->d->host(), out, n, d->tail_threads, results, mv);
-  d->d->last_stats.tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (n_matches) *n_matches = mv.size();
-  if (mv.size() > match_cap) { g_err = "cfr_classify_batch: match buffer too small"; return CFR_ERR_CAPACITY; }
-  if (!mv.empty()) memcpy(matches, mv.data(), mv.size() * sizeof(cfr_match));
-  return CFR_OK;
-}
-
 cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
                               const uint64_t *offsets2, size_t n, cfr_result *results, cfr_match *matches, size_t match_cap,
                               size_t *n_matches) {
   if (!d || (n && (!bases1 || !offsets1 || !results))) return bad_arg("cfr_classify_batch: null argument");
   if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch: bases2/offsets2 must both be given");
   return guarded([&]() -> cfr_status {
-    cfr::DeviceIndex::BatchOut out;
-    d->d->run_batch_host(bases1, offsets1, bases2, offsets2, n, true, out);
-    return finish_classify(d, out, n, results, matches, match_cap, n_matches);
+    d->d->classify_host(bases1, offsets1, bases2, offsets2, n, results, matches, match_cap, n_matches);
+    return CFR_OK;
   });
 }
 
@@ -152,12 +140,14 @@ cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, c
   if (!d || (n && (!d_bases1 || !d_offsets1 || !results))) return bad_arg("cfr_classify_batch_resident: null argument");
   if ((d_bases2 == nullptr) != (d_offsets2 == nullptr)) return bad_arg("cfr_classify_batch_resident: mate buffers must both be given");
   return guarded([&]() -> cfr_status {
-    cfr::DeviceIndex::BatchOut out;
-    d->d->run_batch((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
-                    (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, true, out);
-    return finish_classify(d, out, n, results, matches, match_cap, n_matches);
+    d->d->classify_device((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
+                          (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, results, matches, match_cap, n_matches);
+    return CFR_OK;
   });
 }
+
+void *cfr_host_alloc(size_t bytes) { return cfr::host_alloc_pinned(bytes); }
+void cfr_host_free(void *p) { cfr::host_free_pinned(p); }
 
 cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, const uint64_t *hit_begin, const uint64_t *row_begin,
                                   const uint64_t *row_vals, const int32_t *query_len, size_t n, int threads, cfr_result *results,

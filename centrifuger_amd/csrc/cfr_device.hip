@@ -22,7 +22,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_ENTRIES, S_RESULTS, S_MATCHES, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -34,6 +34,12 @@ template <class T> T *DeviceIndex::dev_alloc(size_t count) {
   owned_.push_back(p);
   device_bytes_ += bytes;
   return (T *)p;
+}
+
+template <class T> T *DeviceIndex::upload(const std::vector<T> &v) {
+  T *d = dev_alloc<T>(v.size());
+  if (!v.empty()) HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
 }
 
 void *DeviceIndex::scratch(size_t slot, size_t bytes) {
@@ -124,6 +130,18 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.sample_rate = (uint32_t)h.sample_rate;
   view_.min_hit_len = h.params.min_hit_len;
   view_.score_adjust = h.score_hit_len_adjust;
+  if (h.params.max_result > 64) throw HipError{"-k / max_result above 64 is not supported by the device tail", -2};
+  view_.max_result = h.params.max_result;
+  view_.tax_parent = upload(h.tax.parent);
+  view_.tax_orig = upload(h.tax.orig_taxid);
+  view_.seq_to_tax = upload(h.tax.seq_to_tax);
+  view_.tax_rank = upload(h.tax.rank);
+  view_.node_cnt = h.tax.node_cnt;
+  view_.seq_cnt = h.tax.seq_cnt;
+  view_.tax_root = h.tax.root;
+  view_.secondary_hit_len = h.params.consider_secondary_hit_len;
+  view_.secondary_factor = h.params.consider_secondary_score_factor;
+  memcpy(view_.rank_num, h.tax.rank_num, sizeof(view_.rank_num));
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }
@@ -132,6 +150,7 @@ DeviceIndex::~DeviceIndex() {
   (void)hipSetDevice(device_);
   for (void *p : owned_) (void)hipFree(p);
   for (auto &s : slots_) if (s.p) (void)hipFree(s.p);
+  if (pinned_) (void)hipHostFree(pinned_);
   for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -202,16 +221,32 @@ size_t scan_tmp_bytes(size_t count) {
 }
 }  // namespace
 
-void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                            uint64_t total1, uint64_t total2, bool want_rows, BatchOut &out) {
-  HIP_CHECK(hipSetDevice(device_));
-  out.hit_begin.assign(n + 1, 0);
-  out.hits.clear();
-  out.row_begin.clear();
-  out.row_vals.clear();
-  out.read_len.assign(n, 0);
-  last_stats = cfr_batch_stats{};
-  if (n == 0) return;
+DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n) {
+  Staged st{nullptr, nullptr, nullptr, nullptr, 0, 0};
+  if (n == 0) return st;
+  st.t1 = o1[n];
+  st.t2 = b2 ? o2[n] : 0;
+  uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, st.t1 + 16);
+  uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
+  if (st.t1) HIP_CHECK(hipMemcpyAsync(d_b1, b1, st.t1, hipMemcpyHostToDevice, stream_));
+  HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  st.b1 = d_b1;
+  st.o1 = d_o1;
+  if (b2) {
+    uint8_t *d_b2 = (uint8_t *)scratch(S_IN_B2, st.t2 + 16);
+    uint64_t *d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
+    if (st.t2) HIP_CHECK(hipMemcpyAsync(d_b2, b2, st.t2, hipMemcpyHostToDevice, stream_));
+    HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+    st.b2 = d_b2;
+    st.o2 = d_o2;
+  }
+  return st;
+}
+
+// search -> adjust/select -> compact -> (enumerate rows -> locate).  Two small D2H syncs (hit and row totals)
+// size the dense arrays; everything else stays on the device.
+void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                    uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -227,8 +262,9 @@ void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uin
   uint64_t *fin_cnt = (uint64_t *)scratch(S_FINCNT, (n + 1) * 8);
   uint64_t *fin_rows = (uint64_t *)scratch(S_FINROWS, cap_total * 8);
   uint64_t *fin_off = (uint64_t *)scratch(S_FINOFF, (n + 1) * 8);
-  const size_t tmp_bytes = std::max(scan_tmp_bytes(n), scan_tmp_bytes(cap_total));
+  size_t tmp_bytes = std::max(scan_tmp_bytes(n), scan_tmp_bytes(cap_total));
   void *tmp = scratch(S_SCAN, tmp_bytes);
+  uint64_t *totals = (uint64_t *)pinned(2 * 8);
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
   HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
@@ -245,83 +281,151 @@ void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uin
   HIP_CHECK(hipGetLastError());
   exclusive_scan(tmp, tmp_bytes, fin_cnt, fin_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[3], stream_));
-  HIP_CHECK(hipMemcpyAsync(out.hit_begin.data(), fin_off, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipMemcpyAsync(&totals[0], fin_off + n, 8, hipMemcpyDeviceToHost, stream_));
+  if (hit_begin_host) {
+    hit_begin_host->resize(n + 1);
+    HIP_CHECK(hipMemcpyAsync(hit_begin_host->data(), fin_off, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+  }
   HIP_CHECK(hipStreamSynchronize(stream_));
-  const uint64_t nhits = out.hit_begin[n];
+  const uint64_t nhits = totals[0];
 
   cfr_hit *hits = (cfr_hit *)scratch(S_HITS, (nhits + 1) * sizeof(cfr_hit));
   uint64_t *rows_per = (uint64_t *)scratch(S_ROWSPER, (nhits + 1) * 8);
   uint64_t *row_off = (uint64_t *)scratch(S_ROWOFF, (nhits + 1) * 8);
   k_compact_hits<<<grid_for(n), kBlock, 0, stream_>>>(n, hit_off, fin_off, fin, fin_rows, hits, rows_per);
   HIP_CHECK(hipGetLastError());
-  out.hits.resize(nhits);
-  if (nhits) HIP_CHECK(hipMemcpyAsync(out.hits.data(), hits, nhits * sizeof(cfr_hit), hipMemcpyDeviceToHost, stream_));
   uint64_t nrows = 0;
+  uint64_t *rows = nullptr, *vals = nullptr;
   HIP_CHECK(hipEventRecord(ev_[4], stream_));
-  HIP_CHECK(hipEventRecord(ev_[5], stream_));
   if (want_rows) {
     HIP_CHECK(hipMemsetAsync(rows_per + nhits, 0, 8, stream_));
-    const size_t tmp2 = scan_tmp_bytes(nhits);
-    void *tmpb = scratch(S_SCAN, std::max(tmp_bytes, tmp2));
-    exclusive_scan(tmpb, std::max(tmp_bytes, tmp2), rows_per, row_off, nhits, stream_);
-    out.row_begin.resize(nhits + 1);
-    HIP_CHECK(hipMemcpyAsync(out.row_begin.data(), row_off, (nhits + 1) * 8, hipMemcpyDeviceToHost, stream_));
+    tmp_bytes = std::max(tmp_bytes, scan_tmp_bytes(nhits));
+    tmp = scratch(S_SCAN, tmp_bytes);
+    exclusive_scan(tmp, tmp_bytes, rows_per, row_off, nhits, stream_);
+    HIP_CHECK(hipMemcpyAsync(&totals[1], row_off + nhits, 8, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
-    nrows = out.row_begin[nhits];
-    uint64_t *rows = (uint64_t *)scratch(S_ROWS, (nrows + 1) * 8);
-    uint64_t *vals = (uint64_t *)scratch(S_ROWVALS, (nrows + 1) * 8);
-    HIP_CHECK(hipEventRecord(ev_[4], stream_));
+    nrows = totals[1];
+    rows = (uint64_t *)scratch(S_ROWS, (nrows + 1) * 8);
+    vals = (uint64_t *)scratch(S_ROWVALS, (nrows + 1) * 8);
     if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, stream_>>>(view_, nhits, hits, row_off, rows);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev_[5], stream_));
     if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, stream_>>>(view_, rows, nrows, vals, nullptr);
     HIP_CHECK(hipGetLastError());
-    out.row_vals.resize(nrows);
-    HIP_CHECK(hipEventRecord(ev_[6], stream_));
-    if (nrows) HIP_CHECK(hipMemcpyAsync(out.row_vals.data(), vals, nrows * 8, hipMemcpyDeviceToHost, stream_));
   } else {
-    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    HIP_CHECK(hipEventRecord(ev_[5], stream_));
   }
-  // query lengths (Classifier.hpp:958-960) from the offsets
-  std::vector<uint64_t> o1(n + 1), o2;
-  HIP_CHECK(hipMemcpyAsync(o1.data(), d_o1, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
-  if (paired) { o2.resize(n + 1); HIP_CHECK(hipMemcpyAsync(o2.data(), d_o2, (n + 1) * 8, hipMemcpyDeviceToHost, stream_)); }
-  HIP_CHECK(hipEventRecord(ev_[7], stream_));
-  HIP_CHECK(hipStreamSynchronize(stream_));
-  for (size_t i = 0; i < n; ++i) {
-    out.read_len[i] = (int32_t)(o1[i + 1] - o1[i]);
-    if (paired) out.read_len[i] += (int32_t)(o2[i + 1] - o2[i]);
-  }
+  HIP_CHECK(hipEventRecord(ev_[6], stream_));
+  p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows};
+  last_stats.n_chains = nchains;
+  last_stats.n_hits = nhits;
+  last_stats.n_rows = nrows;
+}
+
+void DeviceIndex::finish_stats(bool want_rows) {
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev_[a], ev_[b]); return t; };
   last_stats.pack_ms = ms(0, 1);
   last_stats.search_ms = ms(1, 2);
   last_stats.adjust_ms = ms(2, 3);
   last_stats.rows_ms = want_rows ? ms(4, 5) : 0.f;
   last_stats.locate_ms = want_rows ? ms(5, 6) : 0.f;
+  last_stats.tail_ms = ms(6, 7);
   last_stats.total_ms = ms(0, 7);
-  last_stats.n_chains = nchains;
-  last_stats.n_hits = nhits;
-  last_stats.n_rows = nrows;
+}
+
+void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                            uint64_t total1, uint64_t total2, bool want_rows, BatchOut &out) {
+  HIP_CHECK(hipSetDevice(device_));
+  out.hit_begin.assign(n + 1, 0);
+  out.hits.clear();
+  out.row_begin.clear();
+  out.row_vals.clear();
+  out.read_len.assign(n, 0);
+  last_stats = cfr_batch_stats{};
+  if (n == 0) return;
+  Pipe p;
+  run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, want_rows, p, &out.hit_begin);
+  out.hits.resize(p.nhits);
+  if (p.nhits) HIP_CHECK(hipMemcpyAsync(out.hits.data(), p.hits, p.nhits * sizeof(cfr_hit), hipMemcpyDeviceToHost, stream_));
+  if (want_rows) {
+    out.row_begin.resize(p.nhits + 1);
+    HIP_CHECK(hipMemcpyAsync(out.row_begin.data(), p.row_off, (p.nhits + 1) * 8, hipMemcpyDeviceToHost, stream_));
+    out.row_vals.resize(p.nrows);
+    if (p.nrows) HIP_CHECK(hipMemcpyAsync(out.row_vals.data(), p.vals, p.nrows * 8, hipMemcpyDeviceToHost, stream_));
+  }
+  // query lengths (Classifier.hpp:958-960) from the offsets
+  std::vector<uint64_t> o1(n + 1), o2;
+  HIP_CHECK(hipMemcpyAsync(o1.data(), d_o1, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+  if (d_b2) { o2.resize(n + 1); HIP_CHECK(hipMemcpyAsync(o2.data(), d_o2, (n + 1) * 8, hipMemcpyDeviceToHost, stream_)); }
+  HIP_CHECK(hipEventRecord(ev_[7], stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (size_t i = 0; i < n; ++i) {
+    out.read_len[i] = (int32_t)(o1[i + 1] - o1[i]);
+    if (d_b2) out.read_len[i] += (int32_t)(o2[i + 1] - o2[i]);
+  }
+  finish_stats(want_rows);
 }
 
 void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,
                                  bool want_rows, BatchOut &out) {
   HIP_CHECK(hipSetDevice(device_));
-  if (n == 0) { run_batch(nullptr, nullptr, nullptr, nullptr, 0, 0, 0, want_rows, out); return; }
-  const uint64_t t1 = o1[n], t2 = b2 ? o2[n] : 0;
-  uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, t1 + 16);
-  uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
-  if (t1) HIP_CHECK(hipMemcpyAsync(d_b1, b1, t1, hipMemcpyHostToDevice, stream_));
-  HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-  uint8_t *d_b2 = nullptr;
-  uint64_t *d_o2 = nullptr;
-  if (b2) {
-    d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 16);
-    d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
-    if (t2) HIP_CHECK(hipMemcpyAsync(d_b2, b2, t2, hipMemcpyHostToDevice, stream_));
-    HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-  }
-  run_batch(d_b1, d_o1, d_b2, d_o2, n, t1, t2, want_rows, out);
+  Staged st = stage_inputs(b1, o1, b2, o2, n);
+  run_batch(st.b1, st.o1, st.b2, st.o2, n, st.t1, st.t2, want_rows, out);
 }
+
+// Whole Query on the device.  matches: max_result > 0 -> read i owns [i*max_result, ...); otherwise the
+// read's slice of the located-row space.  *match_extent = number of match slots the caller must provide.
+void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                  uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
+                                  size_t *match_extent) {
+  HIP_CHECK(hipSetDevice(device_));
+  last_stats = cfr_batch_stats{};
+  if (match_extent) *match_extent = 0;
+  if (n == 0) return;
+  Pipe p;
+  run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, true, p, nullptr);
+  const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
+  const uint64_t extent = stride ? stride * n : p.nrows;
+  TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
+  cfr_result *d_res = (cfr_result *)scratch(S_RESULTS, n * sizeof(cfr_result));
+  cfr_match *d_match = (cfr_match *)scratch(S_MATCHES, (extent + 1) * sizeof(cfr_match));
+  k_tail<<<grid_for(n, 64), 64, 0, stream_>>>(view_, n, d_o1, d_o2, p.fin_off, p.hits, p.row_off, p.vals, entries, d_res, d_match, stride);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(ev_[7], stream_));
+  if (match_extent) *match_extent = extent;
+  if (extent > match_cap) {
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    finish_stats(true);
+    throw CapacityError{"match buffer too small"};
+  }
+  HIP_CHECK(hipMemcpyAsync(results, d_res, n * sizeof(cfr_result), hipMemcpyDeviceToHost, stream_));
+  if (extent) HIP_CHECK(hipMemcpyAsync(matches, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  finish_stats(true);
+}
+
+void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,
+                                cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent) {
+  HIP_CHECK(hipSetDevice(device_));
+  Staged st = stage_inputs(b1, o1, b2, o2, n);
+  classify_device(st.b1, st.o1, st.b2, st.o2, n, st.t1, st.t2, results, matches, match_cap, match_extent);
+}
+
+void *DeviceIndex::pinned(size_t bytes) {
+  if (pinned_cap_ < bytes) {
+    if (pinned_) (void)hipHostFree(pinned_);
+    pinned_ = nullptr;
+    HIP_CHECK(hipHostMalloc(&pinned_, std::max<size_t>(bytes, 4096), hipHostMallocDefault));
+    pinned_cap_ = std::max<size_t>(bytes, 4096);
+  }
+  return pinned_;
+}
+
+void *host_alloc_pinned(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void host_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
 
 }  // namespace cfr

@@ -34,9 +34,22 @@ struct DevView {            // passed by value to kernels
   int32_t min_hit_len, score_adjust;
   uint64_t max_entries;     // (size_t)(maxResult * maxResultPerHitFactor)
   int32_t locate_all;       // factor <= 0 || maxResult <= 0
+  // taxonomy side tables + tail parameters (Taxonomy.hpp:61-92; Classifier.hpp:17-38)
+  int32_t max_result;
+  const uint64_t *tax_parent, *tax_orig, *seq_to_tax;
+  const uint8_t *tax_rank;
+  uint64_t node_cnt, seq_cnt, tax_root;
+  uint64_t secondary_hit_len;
+  double secondary_factor;
+  uint8_t rank_num[32];
 };
 
+struct TailEntry { uint64_t seq_id, score; int32_t hit_length, k; };
+
 struct HipError { std::string msg; int code; };
+struct CapacityError { std::string msg; };
+void *host_alloc_pinned(size_t bytes);
+void host_free_pinned(void *p);
 
 class DeviceIndex {
  public:
@@ -65,6 +78,14 @@ class DeviceIndex {
   void run_batch(const uint8_t *d_bases1, const uint64_t *d_offs1, const uint8_t *d_bases2, const uint64_t *d_offs2,
                  size_t n, uint64_t total1, uint64_t total2, bool want_rows, BatchOut &out);
 
+  // Full Query on the device: search + locate + tail; results/matches land in caller memory
+  // (fast when that memory came from cfr_host_alloc).  matches: stride entries per read.
+  void classify_device(const uint8_t *d_bases1, const uint64_t *d_offs1, const uint8_t *d_bases2, const uint64_t *d_offs2,
+                       size_t n, uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
+                       size_t *match_extent);
+  void classify_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2, size_t n,
+                     cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent);
+
   // convenience: host buffers -> device, then run_batch
   void run_batch_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2,
                       size_t n, bool want_rows, BatchOut &out);
@@ -73,7 +94,16 @@ class DeviceIndex {
 
  private:
   template <class T> T *dev_alloc(size_t count);
+  template <class T> T *upload(const std::vector<T> &v);
+  struct Staged { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; uint64_t t1, t2; };
+  Staged stage_inputs(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n);
+  // device stages shared by run_batch / classify_device; returns (nhits, nrows) and leaves device pointers in p_
+  struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; };
+  void run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                         uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host);
   void *scratch(size_t slot, size_t bytes);
+  void *pinned(size_t bytes);
+  void finish_stats(bool want_rows);
 
   const HostIndex *host_;
   int device_;
@@ -84,6 +114,8 @@ class DeviceIndex {
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;
   hipEvent_t ev_[8] = {};
+  void *pinned_ = nullptr;
+  size_t pinned_cap_ = 0;
 };
 
 }  // namespace cfr

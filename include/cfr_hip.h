@@ -139,19 +139,27 @@ cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint6
                             const uint8_t *bases2, const uint64_t *offsets2, size_t n,
                             cfr_hit *out_hits, size_t hit_cap, uint64_t *hit_begin);
 
-/* Query for n reads: search + locate on the device, scoring / taxonomy tail, POD results.
- * results: n entries.  matches: capacity match_cap entries, *n_matches = entries used.
- * host buffers in, host buffers out. */
+/* Query for n reads, entirely on the device (search, locate, scoring, LCA / tax-id reduction).
+ * results: n entries.  Matches of read i are matches[results[i].match_begin .. +n_match):
+ *   max_result  > 0: match_begin = i * max_result (slots a read does not use are left untouched);
+ *   max_result <= 0: match_begin = the read's offset in the located-row space.
+ * *n_matches receives the number of match SLOTS the call needs (the extent of the matches array);
+ * CFR_ERR_CAPACITY if match_cap is smaller.  Host buffers in, host buffers out (any host memory works;
+ * memory from cfr_host_alloc is pinned and transfers at PCIe rate). */
 cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
                               const uint8_t *bases2, const uint64_t *offsets2, size_t n,
                               cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
 
-/* Same, with the read buffers ALREADY RESIDENT in this device's HBM (device pointers).
- * This is the entry bench.py times (inputs resident, results returned to host memory). */
+/* Same, with the read buffers ALREADY RESIDENT in this device's HBM (device pointers; the caller has
+ * synchronised whatever produced them).  This is the entry bench.py times. */
 cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1,
                                        const void *d_bases2, const void *d_offsets2, size_t n,
                                        uint64_t total_bases1, uint64_t total_bases2,
                                        cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
+
+/* pinned host memory for result buffers (hipHostMalloc); NULL on failure */
+void *cfr_host_alloc(size_t bytes);
+void cfr_host_free(void *p);
 
 cfr_status cfr_last_batch_stats(const cfr_dev_index *d, cfr_batch_stats *st);
 

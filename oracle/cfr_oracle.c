@@ -371,12 +371,14 @@ static int fm_get_sampled_sa(const ora_fm *fm, uint64_t i, uint64_t *sa, ora_cou
 uint64_t ora_fm_backward_to_sampled_sa(const ora_fm *fm, uint64_t i, uint64_t *l, ora_counters *c) {
   uint64_t ret = 0;
   *l = 0;
-  if (c) c->locates++;
+  uint64_t r0 = 0, a0 = 0;
+  if (c) { c->locates++; r0 = c->bitrank; a0 = c->bitaccess; }
   while (!fm_get_sampled_sa(fm, i, &ret, c)) {
     i = ora_fm_lf(fm, ora_rb_access(&fm->bwt, i, c), i, c);
     if (c) c->lf_steps++;
     ++*l;
   }
+  if (c) { c->bitrank_locate += c->bitrank - r0; c->bitaccess_locate += c->bitaccess - a0; }
   return ret;
 }
 

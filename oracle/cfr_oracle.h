@@ -127,6 +127,7 @@ typedef struct {
 /* operation counters: the N's of SURVEY.md §8(d) "algorithmic bytes" */
 typedef struct {
   uint64_t bitrank, bitaccess, ftab, sampled, filter, hits, bs_calls, extends, lf_steps, locates, read_bases;
+  uint64_t bitrank_locate, bitaccess_locate;   /* the part of bitrank/bitaccess spent inside BackwardToSampledSA */
 } ora_counters;
 
 typedef struct {

@@ -23,16 +23,26 @@ class OraResult(C.Structure):
 
 class OraCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("bitrank", "bitaccess", "ftab", "sampled", "filter", "hits", "bs_calls",
-                                          "extends", "lf_steps", "locates", "read_bases")]
+                                          "extends", "lf_steps", "locates", "read_bases", "bitrank_locate",
+                                          "bitaccess_locate")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
-    def algorithmic_bytes(self, nreads_hits=None):
+    def algorithmic_bytes(self):
         """24 B per bit-rank, 8 B per bit-access, 16 B per ftab lookup, 8 B per sampled-SA read,
-        8 B per selectedSA filter probe, read bytes in, 32 B per hit out."""
+        8 B per selectedSA filter probe, read bytes in, 32 B per hit out.  Whole Query."""
         return (24 * self.bitrank + 8 * self.bitaccess + 16 * self.ftab + 8 * self.sampled + 8 * self.filter
                 + self.read_bases + 32 * self.hits)
+
+    def search_bytes(self):
+        """the share of algorithmic_bytes() spent in SearchForwardAndReverse (kernels k_search_chains + k_adjust_select)"""
+        return (24 * (self.bitrank - self.bitrank_locate) + 8 * (self.bitaccess - self.bitaccess_locate) + 16 * self.ftab
+                + self.read_bases + 32 * self.hits)
+
+    def locate_bytes(self):
+        """the share spent in BackwardToSampledSA (kernel k_locate)"""
+        return 24 * self.bitrank_locate + 8 * self.bitaccess_locate + 8 * self.sampled + 8 * self.filter
 
 
 ORA_HIT_DTYPE = np.dtype([("sp", "<u8"), ("ep", "<u8"), ("l", "<i4"), ("strand", "<i4"), ("offset", "<i4")], align=True)
