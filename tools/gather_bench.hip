@@ -1,0 +1,74 @@
+// gather_bench.hip — what random dependent 16-byte gathers cost on this chip (the access pattern of an
+// FM-index step): every lane chases its own pseudo-random chain through a table of 64-byte records.
+//   ./gather_bench <table_MB> <loads_per_step: 1|2|3> <steps> [record_bytes=64]
+// Reports G steps/s and GB/s of touched 64-byte records.  Used to set the practical roofline in DESIGN.md.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <int LOADS>
+__global__ void chase(const uint64_t *tab, uint64_t nrec, int steps, uint64_t *out) {
+  uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  x = x * 0x9E3779B97F4A7C15ull + 12345;
+  uint64_t acc = 0;
+  for (int s = 0; s < steps; ++s) {
+    const uint64_t r = (x >> 11) % nrec;
+    const uint64_t *rec = tab + r * 8;
+    uint64_t v;
+    if (LOADS == 1) {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec + 2 * (x & 3));
+      v = a.x ^ a.y;
+    } else if (LOADS == 2) {
+      const uint64_t m = rec[x & 3];
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec + 4 + 2 * ((x >> 2) & 1));
+      v = m ^ a.x ^ a.y;
+    } else {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec);
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(rec + 2);
+      const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(rec + 4 + 2 * ((x >> 2) & 1));
+      v = a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
+    }
+    acc += v;
+    x = x * 6364136223846793005ull + 1442695040888963407ull + v;   // next address depends on the loaded data
+  }
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+__global__ void fill(uint64_t *tab, uint64_t nwords) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * blockDim.x)
+    tab[i] = i * 0x9E3779B97F4A7C15ull;
+}
+
+int main(int argc, char **argv) {
+  const uint64_t mb = argc > 1 ? strtoull(argv[1], 0, 10) : 512;
+  const int loads = argc > 2 ? atoi(argv[2]) : 2;
+  const int steps = argc > 3 ? atoi(argv[3]) : 100;
+  const uint64_t lanes = argc > 4 ? strtoull(argv[4], 0, 10) : (uint64_t)256 * 2048 * 8;
+  const uint64_t nrec = mb * 1024 * 1024 / 64;
+  uint64_t *tab, *out;
+  CHECK(hipMalloc(&tab, nrec * 64));
+  CHECK(hipMalloc(&out, lanes * 8));
+  fill<<<4096, 256>>>(tab, nrec * 8);
+  CHECK(hipDeviceSynchronize());
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) {
+    CHECK(hipEventRecord(e0));
+    const unsigned grid = (unsigned)(lanes / 256);
+    if (loads == 1) chase<1><<<grid, 256>>>(tab, nrec, steps, out);
+    else if (loads == 2) chase<2><<<grid, 256>>>(tab, nrec, steps, out);
+    else chase<3><<<grid, 256>>>(tab, nrec, steps, out);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double st = (double)lanes * steps;
+    if (rep == 2)
+      printf("table %6lu MB  loads/step %d  lanes %lu  steps %d : %8.3f ms  %7.2f G steps/s  %8.1f GB/s of 64B records\n",
+             (unsigned long)mb, loads, (unsigned long)lanes, steps, ms, st / ms / 1e6, st * 64 / ms / 1e6);
+  }
+  return 0;
+}
