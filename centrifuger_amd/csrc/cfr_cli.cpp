@@ -1,0 +1,428 @@
+// cfr_cli.cpp — `centrifuger`-compatible command line on top of the C-ABI (include/cfr_hip.h).
+//
+// Drop-in for the reference's classification driver (CentrifugerClass.cpp:342-968) for the options that
+// touch the accelerated path: same option names, same TSV on stdout (ResultWriter.hpp:186-242), same
+// --un/--cl read dumps, same stderr summary lines.  What the reference does with
+// pthread_create(ClassifyReads_Thread) per batch (CentrifugerClass.cpp:681-688) is one
+// cfr_classify_batch call per batch here; batches round-robin over the GPUs given by --gpu, output stays
+// in input order.  Additive options: --gpu LIST|all, --gpu-batch N.
+// Options of the reference that are outside this build (barcode/UMI/read-format/sample-sheet/
+// merge-readpair/expand-taxid) are rejected with a message instead of being silently ignored.
+#include <getopt.h>
+#include <zlib.h>
+
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/cfr_hip.h"
+
+namespace {
+
+const char *kUsage =
+    "./centrifuger [OPTIONS] > output.tsv:\n"
+    "Required:\n"
+    "\t-x FILE: index prefix\n"
+    "\t-1 FILE -2 FILE: paired-end read\n"
+    "\t\tor\n"
+    "\t-u FILE: single-end read\n"
+    "\t\tor\n"
+    "\t-i FILE: interleaved read file\n"
+    "Optional:\n"
+    "\t-t INT: number of host threads (dust masking, TSV formatting) [1]\n"
+    "\t-k INT: report upto <int> distinct, primary assignments for each read pair [1]\n"
+    "\t--un STR: output unclassified reads to files with the prefix of <str>\n"
+    "\t--cl STR: output classified reads to files with the prefix of <str>\n"
+    "\t--no-dust: do not DUST-mask low-complexity regions of reads [mask]\n"
+    "\t--min-hitlen INT: minimum length of partial hits [auto]\n"
+    "\t--hitk-factor INT: resolve at most <int>*k entries for each hit [40; use 0 for no restriction]\n"
+    "\t--consider-secondary STR: in the format INT,FLOAT consider the secondary hit if its hitlen>=INT,score>=FLOAT*best_score [2000,0.995]\n"
+    "\t--gpu LIST: comma separated MI355X ordinals, or 'all' [0]\n"
+    "\t--gpu-batch INT: reads per device batch [1048576]\n"
+    "\t-h: print this usage message\n"
+    "\t-v: print the version information and quit\n";
+
+enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_UNSUPPORTED };
+
+void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp:369-381)
+  char buffer[1024];
+  va_list args;
+  va_start(args, fmt);
+  vsnprintf(buffer, sizeof(buffer), fmt, args);
+  va_end(args);
+  time_t now = time(nullptr);
+  char stime[128];
+  strftime(stime, sizeof(stime), "%c", localtime(&now));
+  fprintf(stderr, "[%s] %s\n", stime, buffer);
+}
+
+// ---- FASTA/FASTQ (optionally gz) record reader; id = first word of the header -----------------
+class SeqReader {
+ public:
+  explicit SeqReader(const std::vector<std::string> &files) : files_(files) {}
+  ~SeqReader() { if (fp_) gzclose(fp_); }
+
+  // returns false at the end of all files
+  bool next(std::string &id, std::string &seq, std::string &qual, bool &has_qual) {
+    for (;;) {
+      if (!fp_) {
+        if (file_idx_ >= files_.size()) return false;
+        const std::string &f = files_[file_idx_++];
+        fp_ = f == "-" ? gzdopen(fileno(stdin), "r") : gzopen(f.c_str(), "r");
+        if (!fp_) { print_log("ERROR: cannot open read file %s", f.c_str()); exit(EXIT_FAILURE); }
+        gzbuffer(fp_, 1 << 20);
+        have_line_ = false;
+      }
+      if (read_record(id, seq, qual, has_qual)) return true;
+      gzclose(fp_);
+      fp_ = nullptr;
+    }
+  }
+
+ private:
+  bool getline(std::string &line) {
+    line.clear();
+    char buf[1 << 16];
+    for (;;) {
+      if (!gzgets(fp_, buf, sizeof(buf))) return !line.empty();
+      size_t n = strlen(buf);
+      bool eol = n && buf[n - 1] == '\n';
+      while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) --n;
+      line.append(buf, n);
+      if (eol) return true;
+    }
+  }
+  bool read_record(std::string &id, std::string &seq, std::string &qual, bool &has_qual) {
+    if (!have_line_) {
+      do { if (!getline(line_)) return false; } while (line_.empty() || (line_[0] != '>' && line_[0] != '@'));
+    }
+    have_line_ = false;
+    const bool fastq = line_[0] == '@';
+    size_t e = 1;
+    while (e < line_.size() && line_[e] != ' ' && line_[e] != '\t') ++e;
+    id.assign(line_, 1, e - 1);
+    // ReadFiles::RemoveReadIdSuffix (ReadFiles.hpp:82-90)
+    if (id.size() >= 2 && id[id.size() - 2] == '/' && (id.back() == '1' || id.back() == '2')) id.resize(id.size() - 2);
+    seq.clear();
+    qual.clear();
+    has_qual = false;
+    while (getline(line_)) {
+      if (line_.empty()) continue;
+      if (line_[0] == '>' || (!fastq && line_[0] == '@')) { have_line_ = true; return true; }
+      if (fastq && line_[0] == '+') {
+        has_qual = true;
+        while (qual.size() < seq.size() && getline(line_)) qual += line_;
+        return true;
+      }
+      if (fastq && line_[0] == '@' && !seq.empty()) { have_line_ = true; return true; }
+      seq += line_;
+    }
+    return true;
+  }
+  std::vector<std::string> files_;
+  size_t file_idx_ = 0;
+  gzFile fp_ = nullptr;
+  std::string line_;
+  bool have_line_ = false;
+};
+
+struct Batch {
+  size_t seq_no = 0;
+  size_t n = 0;
+  bool paired = false;
+  std::vector<std::string> ids, qual1, qual2;
+  std::vector<uint8_t> has_qual;
+  std::vector<uint8_t> bases1, bases2;
+  std::vector<uint64_t> offs1, offs2;
+  std::vector<cfr_result> results;
+  std::vector<cfr_match> matches;
+  std::string tsv;
+  bool done = false;
+};
+
+struct Options {
+  std::string idx;
+  std::vector<std::string> u, m1, m2, inter;
+  int threads = 1;
+  cfr_params params;
+  bool dust = true;
+  std::string un_prefix, cl_prefix;
+  std::vector<int> gpus{0};
+  bool all_gpus = false;
+  size_t gpu_batch = 1u << 20;
+};
+
+// gz read dumps (ResultWriter::SetOutputReads, ResultWriter.hpp:126-176)
+struct ReadDump {
+  gzFile fp[2] = {nullptr, nullptr};
+  void open(const std::string &prefix, bool mate) {
+    if (mate) {
+      fp[0] = gzopen((prefix + "_1.fq.gz").c_str(), "w1");
+      fp[1] = gzopen((prefix + "_2.fq.gz").c_str(), "w1");
+    } else {
+      fp[0] = gzopen((prefix + ".fq.gz").c_str(), "w1");
+    }
+  }
+  void put(int k, const std::string &id, const uint8_t *s, size_t n, const std::string *q) {
+    if (!fp[k]) return;
+    if (!q) gzprintf(fp[k], ">%s\n%.*s\n", id.c_str(), (int)n, (const char *)s);
+    else gzprintf(fp[k], "@%s\n%.*s\n+\n%s\n", id.c_str(), (int)n, (const char *)s, q->c_str());
+  }
+  void close() { for (auto &f : fp) if (f) { gzclose(f); f = nullptr; } }
+};
+
+[[noreturn]] void die_status(const char *what, cfr_status st) {
+  print_log("ERROR: %s failed (status %d): %s", what, st, cfr_last_error());
+  exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+  if (argc <= 1) { fprintf(stderr, "%s", kUsage); return 0; }
+  Options opt;
+  cfr_params_default(&opt.params);
+  static const char *short_options = "x:1:2:u:i:o:t:k:hv";
+  static struct option long_options[] = {
+      {"un", required_argument, 0, OPT_UN}, {"cl", required_argument, 0, OPT_CL}, {"no-dust", no_argument, 0, OPT_NO_DUST},
+      {"min-hitlen", required_argument, 0, OPT_MIN_HITLEN}, {"hitk-factor", required_argument, 0, OPT_HITK},
+      {"consider-secondary", required_argument, 0, OPT_SECONDARY}, {"gpu", required_argument, 0, OPT_GPU},
+      {"gpu-batch", required_argument, 0, OPT_GPU_BATCH},
+      {"sample-sheet", required_argument, 0, OPT_UNSUPPORTED}, {"merge-readpair", no_argument, 0, OPT_UNSUPPORTED},
+      {"expand-taxid", no_argument, 0, OPT_UNSUPPORTED}, {"read-format", required_argument, 0, OPT_UNSUPPORTED},
+      {"barcode", required_argument, 0, OPT_UNSUPPORTED}, {"UMI", required_argument, 0, OPT_UNSUPPORTED},
+      {"barcode-whitelist", required_argument, 0, OPT_UNSUPPORTED}, {"barcode-translate", required_argument, 0, OPT_UNSUPPORTED},
+      {0, 0, 0, 0}};
+  int c, option_index = 0;
+  while ((c = getopt_long(argc, argv, short_options, long_options, &option_index)) != -1) {
+    switch (c) {
+      case 'x': opt.idx = optarg; break;
+      case 'u': opt.u.push_back(optarg); break;
+      case '1': opt.m1.push_back(optarg); break;
+      case '2': opt.m2.push_back(optarg); break;
+      case 'i': opt.inter.push_back(optarg); break;
+      case 'o': break;   // accepted and unused, like the reference
+      case 't': opt.threads = atoi(optarg); break;
+      case 'k': opt.params.max_result = atoi(optarg); break;
+      case 'v': printf("Centrifuger-MI355X %s\n", cfr_version()); return 0;
+      case OPT_UN: opt.un_prefix = optarg; break;
+      case OPT_CL: opt.cl_prefix = optarg; break;
+      case OPT_NO_DUST: opt.dust = false; break;
+      case OPT_MIN_HITLEN: opt.params.min_hit_len = atoi(optarg); break;
+      case OPT_HITK: opt.params.max_result_per_hit_factor = atoi(optarg); break;
+      case OPT_SECONDARY: {
+        unsigned long hl; double f;
+        if (sscanf(optarg, "%lu,%lf", &hl, &f) != 2) {
+          print_log("Invalid format for --consider-secondary option. It should be in the format of INT,FLOAT");
+          return EXIT_FAILURE;
+        }
+        opt.params.consider_secondary_hit_len = hl;
+        opt.params.consider_secondary_score_factor = f;
+        break;
+      }
+      case OPT_GPU:
+        if (!strcmp(optarg, "all")) opt.all_gpus = true;
+        else {
+          opt.gpus.clear();
+          for (char *tok = strtok(optarg, ","); tok; tok = strtok(nullptr, ",")) opt.gpus.push_back(atoi(tok));
+        }
+        break;
+      case OPT_GPU_BATCH: opt.gpu_batch = strtoull(optarg, nullptr, 10); break;
+      case OPT_UNSUPPORTED:
+        print_log("ERROR: option --%s belongs to a part of Centrifuger outside the MI355X classification path and is not available in this build.",
+                  long_options[option_index].name);
+        return EXIT_FAILURE;
+      default: fprintf(stderr, "%s", kUsage); return EXIT_FAILURE;
+    }
+  }
+  print_log("Centrifuger-MI355X (%s) starts.", cfr_version());
+  if (opt.idx.empty()) { print_log("Need to use -x to specify index prefix."); return EXIT_FAILURE; }
+  if (opt.threads < 1) opt.threads = 1;
+  if (opt.gpu_batch < 1) opt.gpu_batch = 1;
+  const bool paired = !opt.m1.empty() || !opt.inter.empty();
+  if (opt.m1.size() != opt.m2.size()) { print_log("ERROR: -1 and -2 must be given the same number of times."); return EXIT_FAILURE; }
+  if (opt.u.empty() && !paired) { print_log("Need to use -u/-1/-2/-i to specify input reads."); return EXIT_FAILURE; }
+
+  cfr_index *idx = nullptr;
+  cfr_status st = cfr_index_open(opt.idx.c_str(), &opt.params, &idx);
+  if (st != CFR_OK) die_status("loading the index", st);
+  cfr_index_info info;
+  cfr_index_get_info(idx, &info);
+  print_log("Finishes loading index.");
+  if (opt.params.min_hit_len <= 0) print_log("Inferred --min-hitlen: %d", info.min_hit_len);
+  if (opt.all_gpus) {
+    int cnt = 0;
+    cfr_device_count(&cnt);
+    opt.gpus.clear();
+    for (int g = 0; g < cnt; ++g) opt.gpus.push_back(g);
+  }
+  std::vector<cfr_dev_index *> devs;
+  for (int g : opt.gpus) {
+    cfr_dev_index *d = nullptr;
+    st = cfr_device_index_create(idx, g, &d);
+    if (st != CFR_OK) die_status("creating the device index (this build has no CPU fallback)", st);
+    devs.push_back(d);
+  }
+  if (devs.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }
+
+  ReadDump un, cl;
+  if (!opt.un_prefix.empty()) un.open(opt.un_prefix, paired);
+  if (!opt.cl_prefix.empty()) cl.open(opt.cl_prefix, paired);
+  fputs(cfr_tsv_header(), stdout);
+
+  // ---- pipeline: reader -> device workers (one per GPU) -> ordered writer (this thread)
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::shared_ptr<Batch>> pending;      // parsed, waiting for a device
+  std::deque<std::shared_ptr<Batch>> in_order;     // every batch in input order, for the writer
+  bool reader_done = false;
+  const size_t max_inflight = devs.size() * 2 + 1;
+
+  std::thread reader([&]() {
+    std::unique_ptr<SeqReader> r1, r2;
+    const bool interleaved = !opt.inter.empty();
+    if (interleaved) r1.reset(new SeqReader(opt.inter));
+    else if (paired) { r1.reset(new SeqReader(opt.m1)); r2.reset(new SeqReader(opt.m2)); }
+    else r1.reset(new SeqReader(opt.u));
+    size_t seq_no = 0;
+    bool more = true;
+    while (more) {
+      auto b = std::make_shared<Batch>();
+      b->seq_no = seq_no++;
+      b->paired = paired;
+      b->offs1.push_back(0);
+      if (paired) b->offs2.push_back(0);
+      std::string id, s, q, id2, s2, q2;
+      bool hq = false, hq2 = false;
+      while (b->n < opt.gpu_batch) {
+        if (!r1->next(id, s, q, hq)) { more = false; break; }
+        if (paired) {
+          bool ok = interleaved ? r1->next(id2, s2, q2, hq2) : r2->next(id2, s2, q2, hq2);
+          if (!ok) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+          b->bases2.insert(b->bases2.end(), s2.begin(), s2.end());
+          b->offs2.push_back(b->bases2.size());
+          b->qual2.push_back(hq2 ? q2 : std::string());
+        }
+        b->ids.push_back(id);
+        b->bases1.insert(b->bases1.end(), s.begin(), s.end());
+        b->offs1.push_back(b->bases1.size());
+        b->qual1.push_back(hq ? q : std::string());
+        b->has_qual.push_back(hq ? 1 : 0);
+        ++b->n;
+      }
+      if (!more && paired && !interleaved) {
+        if (r2->next(id2, s2, q2, hq2)) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+      }
+      if (b->n == 0) break;
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return in_order.size() < max_inflight; });
+      pending.push_back(b);
+      in_order.push_back(b);
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    reader_done = true;
+    cv.notify_all();
+  });
+
+  auto worker = [&](cfr_dev_index *dev) {
+    for (;;) {
+      std::shared_ptr<Batch> b;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !pending.empty() || reader_done; });
+        if (pending.empty()) return;
+        b = pending.front();
+        pending.pop_front();
+      }
+      if (opt.dust) {   // CentrifugerClass.cpp:276-316
+        cfr_dust_mask_batch(b->bases1.data(), b->offs1.data(), b->n, opt.threads);
+        if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data(), b->n, opt.threads);
+      }
+      b->results.resize(b->n);
+      size_t cap = b->n * (size_t)(opt.params.max_result > 0 ? opt.params.max_result : 4) + 16, used = 0;
+      for (;;) {
+        b->matches.resize(cap);
+        cfr_status s = cfr_classify_batch(dev, b->bases1.data(), b->offs1.data(), b->paired ? b->bases2.data() : nullptr,
+                                          b->paired ? b->offs2.data() : nullptr, b->n, b->results.data(), b->matches.data(), cap, &used);
+        if (s == CFR_ERR_CAPACITY) { cap = used + 16; continue; }
+        if (s != CFR_OK) die_status("cfr_classify_batch", s);
+        break;
+      }
+      // TSV rows (ResultWriter::Output), formatted in parallel slices then concatenated in order
+      const int nt = (int)std::min<size_t>((size_t)opt.threads, std::max<size_t>(1, b->n / 4096));
+      std::vector<std::string> parts((size_t)nt);
+      auto fmt = [&](int t) {
+        const size_t lo = b->n * (size_t)t / (size_t)nt, hi = b->n * (size_t)(t + 1) / (size_t)nt;
+        std::string &out = parts[(size_t)t];
+        char buf[8192];
+        for (size_t i = lo; i < hi; ++i) {
+          size_t w = cfr_format_tsv(idx, b->ids[i].c_str(), &b->results[i], b->matches.data(), buf, sizeof(buf));
+          if (w < sizeof(buf)) out.append(buf, w);
+          else {
+            std::string big(w + 1, '\0');
+            cfr_format_tsv(idx, b->ids[i].c_str(), &b->results[i], b->matches.data(), &big[0], big.size());
+            out.append(big.data(), w);
+          }
+        }
+      };
+      if (nt == 1) fmt(0);
+      else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t) th.emplace_back(fmt, t);
+        for (auto &x : th) x.join();
+      }
+      for (auto &p : parts) b->tsv += p;
+      std::lock_guard<std::mutex> lk(mu);
+      b->done = true;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> workers;
+  for (cfr_dev_index *d : devs) workers.emplace_back(worker, d);
+
+  size_t total = 0, classified = 0;
+  for (;;) {
+    std::shared_ptr<Batch> b;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&]() { return (!in_order.empty() && in_order.front()->done) || (reader_done && in_order.empty()); });
+      if (in_order.empty()) break;
+      b = in_order.front();
+      in_order.pop_front();
+      cv.notify_all();
+    }
+    fwrite(b->tsv.data(), 1, b->tsv.size(), stdout);
+    for (size_t i = 0; i < b->n; ++i) {
+      const bool hit = b->results[i].n_match > 0;
+      ++total;
+      classified += hit ? 1 : 0;
+      ReadDump *dump = hit ? (cl.fp[0] ? &cl : nullptr) : (un.fp[0] ? &un : nullptr);
+      if (!dump) continue;
+      dump->put(0, b->ids[i], b->bases1.data() + b->offs1[i], b->offs1[i + 1] - b->offs1[i], b->has_qual[i] ? &b->qual1[i] : nullptr);
+      if (b->paired)
+        dump->put(1, b->ids[i], b->bases2.data() + b->offs2[i], b->offs2[i + 1] - b->offs2[i], b->qual2[i].empty() ? nullptr : &b->qual2[i]);
+    }
+  }
+  reader.join();
+  for (auto &w : workers) w.join();
+  un.close();
+  cl.close();
+  fflush(stdout);
+  // ResultWriter::Finalize (ResultWriter.hpp:279-283)
+  print_log("Processed %lu read fragments, and %lu (%.2lf%%) can be classified.", (unsigned long)total, (unsigned long)classified,
+            total ? (double)classified / (double)total * 100.0 : 0.0);
+  for (auto *d : devs) cfr_device_index_destroy(d);
+  cfr_index_destroy(idx);
+  print_log("Centrifuger finishes.");
+  return 0;
+}

@@ -1,0 +1,63 @@
+"""The `centrifuger`-compatible command line (centrifuger_amd/bin/centrifuger) against the reference's TSV
+and read dumps.  -m gpu."""
+import gzip
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, REF_DIR, ROOT, have_ref
+
+pytestmark = pytest.mark.gpu
+MAN = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+CLI = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
+
+
+def _args(args, gd):
+    return [os.path.join(gd, a) if a.endswith((".fq", ".fa")) else a for a in args]
+
+
+@pytest.mark.parametrize("case", sorted(MAN["cases"]))
+def test_cli_stdout_equals_reference_tsv(case, golden_dir):
+    c = MAN["cases"][case]
+    out = subprocess.run([CLI, "-x", os.path.join(golden_dir, c["index"]), "-t", "3", "--gpu-batch", "97"] + _args(c["args"], golden_dir),
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.stdout == open(os.path.join(GOLDEN, "tsv", case + ".tsv"), "rb").read()
+    assert b"can be classified." in out.stderr and b"Centrifuger finishes." in out.stderr
+
+
+def test_cli_gz_input_interleaved_and_batches(golden_dir, tmp_path):
+    # interleave pe_1/pe_2 into one gz file; result must equal the -1/-2 golden
+    l1 = open(os.path.join(golden_dir, "pe_1.fq"), "rb").read().split(b"\n")
+    l2 = open(os.path.join(golden_dir, "pe_2.fq"), "rb").read().split(b"\n")
+    inter = []
+    for i in range(0, len(l1) - 1, 4):
+        inter += l1[i:i + 4] + l2[i:i + 4]
+    p = tmp_path / "inter.fq.gz"
+    with gzip.open(p, "wb") as f:
+        f.write(b"\n".join(inter) + b"\n")
+    out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-i", str(p), "-k", "5", "--gpu-batch", "33"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert out == open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
+def test_cli_read_dumps_match_reference(golden_dir, tmp_path):
+    for tool, tag in ((os.path.join(REF_DIR, "centrifuger"), "ref"), (CLI, "gpu")):
+        subprocess.run([tool, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "edge.fa"),
+                        "--un", str(tmp_path / f"{tag}_un"), "--cl", str(tmp_path / f"{tag}_cl")],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([tool, "-x", os.path.join(golden_dir, "f6"), "-1", os.path.join(golden_dir, "pe_1.fq"), "-2",
+                        os.path.join(golden_dir, "pe_2.fq"), "--un", str(tmp_path / f"{tag}_pun"), "--cl", str(tmp_path / f"{tag}_pcl")],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for name in ("un.fq.gz", "cl.fq.gz", "pun_1.fq.gz", "pun_2.fq.gz", "pcl_1.fq.gz", "pcl_2.fq.gz"):
+        assert gzip.open(tmp_path / f"gpu_{name}").read() == gzip.open(tmp_path / f"ref_{name}").read(), name
+
+
+def test_cli_rejects_out_of_scope_options_and_missing_index(golden_dir):
+    r = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq"), "--merge-readpair"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"not available in this build" in r.stderr
+    r = subprocess.run([CLI, "-x", "/nonexistent/idx", "-u", os.path.join(golden_dir, "se.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"loading the index" in r.stderr
