@@ -95,6 +95,47 @@ def make_reads_gpu(torch, cat_d, starts, n_reads, read_len, seed, device, sub_ra
     return out
 
 
+def make_pairs_gpu(torch, cat_d, starts, n_pairs, read_len, seed, device, ins_lo=250, ins_hi=500, sub_rate=0.01, n_rate=0.001):
+    """FR pairs, insert U[250,500] (BASELINE configs[2]); mate 2 is the reverse complement of the fragment's far end."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    starts_d = torch.as_tensor(starts, device=device)
+    lens = starts_d[1:] - starts_d[:-1]
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for i, a in enumerate(b"ACGT"):
+        code[a] = i
+    ar = torch.arange(read_len, device=device)
+    out1 = torch.empty((n_pairs, read_len), dtype=torch.uint8, device=device)
+    out2 = torch.empty((n_pairs, read_len), dtype=torch.uint8, device=device)
+
+    def mutate(r, m):
+        sub = torch.rand((m, read_len), generator=gen, device=device) < sub_rate
+        shift = torch.randint(1, 4, (m, read_len), generator=gen, device=device)
+        r = torch.where(sub, acgt[(code[r.long()] + shift) & 3], r)
+        isn = torch.rand((m, read_len), generator=gen, device=device) < n_rate
+        return torch.where(isn, torch.full_like(r, ord("N")), r)
+
+    chunk = 1 << 20
+    for lo in range(0, n_pairs, chunk):
+        m = min(chunk, n_pairs - lo)
+        gi = torch.randint(0, len(lens), (m,), generator=gen, device=device)
+        ins = torch.randint(ins_lo, ins_hi + 1, (m,), generator=gen, device=device)
+        pos = (torch.rand(m, generator=gen, device=device, dtype=torch.float64) * (lens[gi] - ins).double()).long()
+        base = starts_d[gi] + pos
+        left = cat_d[base[:, None] + ar[None, :]]
+        right = comp[cat_d[(base + ins - read_len)[:, None] + ar[None, :]].long()].flip(1)
+        flip = torch.rand(m, generator=gen, device=device) < 0.5
+        r1 = torch.where(flip[:, None], right, left)
+        r2 = torch.where(flip[:, None], left, right)
+        out1[lo:lo + m] = mutate(r1, m)
+        out2[lo:lo + m] = mutate(r2, m)
+    return out1, out2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +152,9 @@ def main():
     ap.add_argument("--build-threads", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
+    ap.add_argument("--mode", choices=["se", "pe"], default="se",
+                    help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5")
+    ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
     args = ap.parse_args()
 
     import torch
@@ -137,7 +181,9 @@ def main():
     prefix = os.path.join(cache, "idx")
 
     t0 = time.time()
-    idx = capi.Index(prefix)
+    paired = args.mode == "pe"
+    k = args.k if args.k is not None else (5 if paired else 1)
+    idx = capi.Index(prefix, capi.default_params(max_result=k))
     dev = capi.DeviceIndex(idx, local_rank)
     info = dev.info()
     log(f"rank {rank}: index n={info.n} b={info.block_size} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
@@ -145,16 +191,23 @@ def main():
     cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     starts = np.load(os.path.join(cache, "genome_starts.npy"))
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
-    reads_d = make_reads_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
+    if paired:
+        reads_d, reads2_d = make_pairs_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
+    else:
+        reads_d = make_reads_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
+        reads2_d = None
     del cat_d
     offs_d = (torch.arange(args.reads + 1, device=device, dtype=torch.int64) * args.read_len)
     torch.cuda.synchronize()
     total_bases = args.reads * args.read_len
     res_pin = capi.PinnedArray(args.reads, capi.RESULT_DTYPE)     # cfr_host_alloc: D2H at PCIe rate
-    mat_pin = capi.PinnedArray(args.reads, capi.MATCH_DTYPE)
+    mat_pin = capi.PinnedArray(args.reads * k, capi.MATCH_DTYPE)
     results, matches = res_pin.array, mat_pin.array
 
     def step():
+        if paired:
+            return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, reads2_d.data_ptr(),
+                                         offs_d.data_ptr(), total_bases, results=results, matches=matches)
         return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, results=results, matches=matches)
 
     for _ in range(args.warmup):
@@ -186,11 +239,11 @@ def main():
     value = total_reads / elapsed
     search_ms = float(np.mean([s.search_ms for s in kstats]))
     out = {
-        "metric": "classified reads/sec (150 bp)", "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+        "metric": "classified reads/sec (150 bp)", "value": value, "unit": "read pairs/s" if paired else "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), "
-                               f"{args.reads} x {args.read_len} bp SE reads per step per GPU, -k 1, inputs resident in HBM",
+                               f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM",
                    "index_bp": int(info.n), "reads_per_step_per_gpu": args.reads, "read_len": args.read_len,
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective"},
         "classified_fraction": classified / args.reads,
@@ -202,10 +255,11 @@ def main():
     import oracle_lib as ora
     ns = min(args.count_sample, args.reads)
     sample = reads_d[:ns].cpu().numpy().reshape(-1)
+    sample2 = reads2_d[:ns].cpu().numpy().reshape(-1) if paired else None
     soffs = (np.arange(ns + 1, dtype=np.uint64) * np.uint64(args.read_len))
-    o = ora.OracleIndex(prefix)
+    o = ora.OracleIndex(prefix, max_result=k)
     threads = min(os.cpu_count() or 1, 64)
-    ores, cnt = o.classify(sample, soffs, threads=threads, counters=True)
+    ores, cnt = o.classify(sample, soffs, sample2, soffs if paired else None, threads=threads, counters=True)
     c = cnt.as_dict()
     # bytes of the search kernel = everything except the locate part (sampled/filter reads and the LF-walk ranks);
     # the LF walk costs per step 1 Access + 1 Rank on the run-block structure: count it separately
@@ -237,20 +291,34 @@ def main():
         synth.write_fasta(rs, fa)
         one = os.path.join(cache, "one.fa")
         synth.write_fasta(rs.slice(0, 1), one)
+        files, files_one = ["-u", fa], ["-u", one]
+        rs2 = None
+        if paired:
+            rs2 = synth.ReadSet(reads2_d[:nb].cpu().numpy().reshape(-1), rs.offsets.copy())
+            fa2 = os.path.join(cache, f"sample_{rank}_2.fa")
+            synth.write_fasta(rs2, fa2)
+            one2 = os.path.join(cache, "one_2.fa")
+            synth.write_fasta(rs2.slice(0, 1), one2)
+            files, files_one = ["-1", fa, "-2", fa2], ["-1", one, "-2", one2]
         t0 = time.time()
-        subprocess.run([refbin, "-x", prefix, "-u", one, "-t", str(ncpu)], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        subprocess.run([refbin, "-x", prefix, "-t", str(ncpu), "-k", str(k)] + files_one, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         t_load = time.time() - t0
         t0 = time.time()
-        ref_tsv = subprocess.run([refbin, "-x", prefix, "-u", fa, "-t", str(ncpu)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        ref_tsv = subprocess.run([refbin, "-x", prefix, "-t", str(ncpu), "-k", str(k)] + files, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
         t_full = time.time() - t0
         cpu_rate = nb / max(t_full - t_load, 1e-9)
         # GPU TSV on the same sample (dust applied on the host exactly like the reference does)
         b = rs.bases.copy()
         capi.dust_mask(b, rs.offsets, threads=min(ncpu, 64))
-        r2, m2 = dev.classify(b, rs.offsets)
+        if paired:
+            bb2 = rs2.bases.copy()
+            capi.dust_mask(bb2, rs2.offsets, threads=min(ncpu, 64))
+            r2, m2 = dev.classify(b, rs.offsets, bb2, rs2.offsets)
+        else:
+            r2, m2 = dev.classify(b, rs.offsets)
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
         out["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": ncpu, "kind": "reference",
-                               "sample": f"first {nb} reads of the step batch, oracle/_ref/centrifuger -t {ncpu}, "
+                               "sample": f"first {nb} {'pairs' if paired else 'reads'} of the step batch, oracle/_ref/centrifuger -t {ncpu} -k {k}, "
                                          f"wall {t_full:.1f}s minus index-load run {t_load:.1f}s (end-to-end incl. FASTA parse, dust, TSV)"}
         out["parity"] = {"reads": nb, "tsv_identical_to_reference": gpu_tsv == ref_tsv,
                          "md5": hashlib.md5(gpu_tsv).hexdigest()}
