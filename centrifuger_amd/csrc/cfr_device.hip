@@ -4,6 +4,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "cfr_kernels.hip.inc"
@@ -142,6 +143,26 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.secondary_hit_len = h.params.consider_secondary_hit_len;
   view_.secondary_factor = h.params.consider_secondary_score_factor;
   memcpy(view_.rank_num, h.tax.rank_num, sizeof(view_.rank_num));
+  // derived wide ftab (cfr_device.hpp): K chosen so the table stays a small fraction of HBM; CFR_FTABX_WIDTH overrides (0 = off)
+  view_.ftabx = nullptr;
+  view_.ftabx_width = 0;
+  {
+    // auto: about one K-mer per text position, at least 2 characters wider than the on-disk ftab, at most 14 (4.3 GB)
+    uint32_t log4n = 0;
+    while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
+    uint32_t K = std::min<uint32_t>(14, std::max<uint32_t>(view_.ftab_width + 2, log4n + 1));
+    if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
+    if (K > 16) K = 16;
+    if (K > view_.ftab_width && view_.ftab_width > 0) {
+      const uint64_t entries = 1ull << (2 * K);
+      uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2);
+      k_build_ftabx<<<(unsigned)((entries + 255) / 256), 256, 0, stream_>>>(view_, K, d_tab);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      view_.ftabx = d_tab;
+      view_.ftabx_width = K;
+    }
+  }
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }

@@ -8,6 +8,9 @@
 //              => FMIndex::Rank(c, p) / Sequence::Access(p) touch exactly ONE 64-byte record:
 //                 8 B (mid[c]) + 16 B (the half that holds symbol p).
 //   ftab     : (start, count) u64 pairs, 4^w entries          (FMIndex.hpp:27)
+//   ftabx    : DERIVED at load time, never on disk: for every K-mer (K = 12..16 > w) the exact state
+//              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
+//              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
 //   sel_rows / sel_vals : sorted selectedSA pairs             (FMIndex.hpp:34)
 #pragma once
@@ -27,6 +30,8 @@ struct DevView {            // passed by value to kernels
   uint64_t C[5];
   const uint64_t *occ;      // 8 u64 per record
   const uint64_t *ftab;     // 2 u64 per entry
+  const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l); nullptr = off
+  uint32_t ftabx_width;     // K (> ftab_width)
   const uint64_t *sampled;
   const uint64_t *sel_rows, *sel_vals;
   uint64_t sel_cnt;

@@ -304,7 +304,7 @@ uint64_t ora_fm_rank(const ora_fm *fm, char ch, uint64_t p, int inclusive, ora_c
 void ora_fm_backward_extend(const ora_fm *fm, char ch, uint64_t sp, uint64_t ep,
                             uint64_t *nsp, uint64_t *nep, ora_counters *c) {
   uint64_t offset = fm->C[fm->plainCoder.code[(unsigned char)ch]];
-  if (c) c->extends++;
+  if (c) { c->extends++; if (sp == ep) c->ext_single_row++; else if ((sp >> 7) != (ep >> 7)) c->ext_two_records++; }
   *nsp = offset + ora_fm_rank(fm, ch, sp, 0, c) + 1 - 1;
   if (sp != ep) *nep = offset + ora_fm_rank(fm, ch, ep, 1, c) - 1;
   else *nep = *nsp + ((ora_rb_access(&fm->bwt, ep, c) == ch) ? 0 : (uint64_t)-1);

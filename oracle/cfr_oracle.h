@@ -128,6 +128,7 @@ typedef struct {
 typedef struct {
   uint64_t bitrank, bitaccess, ftab, sampled, filter, hits, bs_calls, extends, lf_steps, locates, read_bases;
   uint64_t bitrank_locate, bitaccess_locate;   /* the part of bitrank/bitaccess spent inside BackwardToSampledSA */
+  uint64_t ext_single_row, ext_two_records;    /* extends with sp==ep / with sp,ep in different 128-row blocks */
 } ora_counters;
 
 typedef struct {

@@ -24,7 +24,7 @@ class OraResult(C.Structure):
 class OraCounters(C.Structure):
     _fields_ = [(k, C.c_uint64) for k in ("bitrank", "bitaccess", "ftab", "sampled", "filter", "hits", "bs_calls",
                                           "extends", "lf_steps", "locates", "read_bases", "bitrank_locate",
-                                          "bitaccess_locate")]
+                                          "bitaccess_locate", "ext_single_row", "ext_two_records")]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
