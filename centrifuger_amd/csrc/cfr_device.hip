@@ -63,6 +63,11 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   for (auto &e : ev_) HIP_CHECK(hipEventCreate(&e));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char *e = getenv("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
+  if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
 
   // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp)
   const uint64_t nrec = (h.n >> 7) + 2;
@@ -156,7 +161,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     if (K > view_.ftab_width && view_.ftab_width > 0) {
       const uint64_t entries = 1ull << (2 * K);
       uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2);
-      k_build_ftabx<<<(unsigned)((entries + 255) / 256), 256, 0, stream_>>>(view_, K, d_tab);
+      k_build_ftabx<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, K, d_tab);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
       view_.ftabx = d_tab;
@@ -292,8 +297,15 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
   exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[1], stream_));
-  if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
-  else k_search_chains<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
+  if (search_v1_) {
+    if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
+    else k_search_chains<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
+  } else {
+    // persistent grid: every lane walks chains gid, gid + T, ... (T = resident lanes), see k_search_chains_v2
+    const unsigned blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * blocks_per_cu_));
+    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, total1, total2, hit_off, raw, chain_cnt);
+    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, total1, 0, hit_off, raw, chain_cnt);
+  }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
   HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, stream_));

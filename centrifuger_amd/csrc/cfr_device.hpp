@@ -119,6 +119,8 @@ class DeviceIndex {
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;
   hipEvent_t ev_[8] = {};
+  int num_cus_ = 256, blocks_per_cu_ = 5;
+  bool search_v1_ = false;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
 };
