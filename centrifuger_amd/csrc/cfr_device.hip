@@ -23,7 +23,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_ENTRIES, S_RESULTS, S_MATCHES, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -62,7 +62,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   if (device < 0 || device >= count) throw HipError{"device ordinal out of range", -1};
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-  for (auto &e : ev_) HIP_CHECK(hipEventCreate(&e));
+  for (auto &set : evs_) for (auto &e : set) HIP_CHECK(hipEventCreate(&e));
+  ev_ = evs_[0];
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+  for (auto &e : tail_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -168,6 +173,27 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       view_.ftabx_width = K;
     }
   }
+  // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
+  view_.loc_memo = nullptr;
+  view_.memo_shift = 0;
+  {
+    double budget_gb = 16.0;
+    if (const char *e = getenv("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
+    uint64_t max_val = h.adjusted_sa0;
+    for (uint64_t x : h.selected_vals) max_val = std::max(max_val, x);
+    const bool fits32 = h.sampled_bits <= 32 && max_val <= 0xffffffffull;
+    uint32_t shift = 0;
+    while (shift < 8 && (double)((h.n >> shift) + 1) * 4.0 > budget_gb * 1e9) ++shift;
+    if (budget_gb > 0 && fits32 && (1u << shift) < (uint32_t)h.sample_rate) {
+      const uint64_t entries = ((h.n - 1) >> shift) + 1;
+      uint32_t *d_memo = dev_alloc<uint32_t>(entries);
+      k_build_loc_memo<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, shift, entries, d_memo);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      view_.loc_memo = d_memo;
+      view_.memo_shift = shift;
+    }
+  }
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }
@@ -177,7 +203,10 @@ DeviceIndex::~DeviceIndex() {
   for (void *p : owned_) (void)hipFree(p);
   for (auto &s : slots_) if (s.p) (void)hipFree(s.p);
   if (pinned_) (void)hipHostFree(pinned_);
-  for (auto &e : ev_) if (e) (void)hipEventDestroy(e);
+  for (auto &set : evs_) for (auto &e : set) if (e) (void)hipEventDestroy(e);
+  for (auto &e : tail_done_) if (e) (void)hipEventDestroy(e);
+  for (auto &e : copy_done_) if (e) (void)hipEventDestroy(e);
+  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -350,20 +379,20 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   }
   HIP_CHECK(hipEventRecord(ev_[6], stream_));
   p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows};
-  last_stats.n_chains = nchains;
-  last_stats.n_hits = nhits;
-  last_stats.n_rows = nrows;
+  last_stats.n_chains += nchains;
+  last_stats.n_hits += nhits;
+  last_stats.n_rows += nrows;
 }
 
 void DeviceIndex::finish_stats(bool want_rows) {
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev_[a], ev_[b]); return t; };
-  last_stats.pack_ms = ms(0, 1);
-  last_stats.search_ms = ms(1, 2);
-  last_stats.adjust_ms = ms(2, 3);
-  last_stats.rows_ms = want_rows ? ms(4, 5) : 0.f;
-  last_stats.locate_ms = want_rows ? ms(5, 6) : 0.f;
-  last_stats.tail_ms = ms(6, 7);
-  last_stats.total_ms = ms(0, 7);
+  last_stats.pack_ms += ms(0, 1);
+  last_stats.search_ms += ms(1, 2);
+  last_stats.adjust_ms += ms(2, 3);
+  last_stats.rows_ms += want_rows ? ms(4, 5) : 0.f;
+  last_stats.locate_ms += want_rows ? ms(5, 6) : 0.f;
+  last_stats.tail_ms += ms(6, 7);
+  last_stats.total_ms += ms(0, 7);
 }
 
 void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
@@ -408,6 +437,7 @@ void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const ui
 
 // Whole Query on the device.  matches: max_result > 0 -> read i owns [i*max_result, ...); otherwise the
 // read's slice of the located-row space.  *match_extent = number of match slots the caller must provide.
+// The batch is cut into sub-batches: the D2H copy of sub-batch k (copy stream) overlaps the kernels of k+1.
 void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
                                   size_t *match_extent) {
@@ -415,26 +445,40 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   last_stats = cfr_batch_stats{};
   if (match_extent) *match_extent = 0;
   if (n == 0) return;
-  Pipe p;
-  run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, true, p, nullptr);
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
-  const uint64_t extent = stride ? stride * n : p.nrows;
-  TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
-  cfr_result *d_res = (cfr_result *)scratch(S_RESULTS, n * sizeof(cfr_result));
-  cfr_match *d_match = (cfr_match *)scratch(S_MATCHES, (extent + 1) * sizeof(cfr_match));
-  k_tail<<<grid_for(n, 64), 64, 0, stream_>>>(view_, n, d_o1, d_o2, p.fin_off, p.hits, p.row_off, p.vals, entries, d_res, d_match, stride);
-  HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventRecord(ev_[7], stream_));
-  if (match_extent) *match_extent = extent;
-  if (extent > match_cap) {
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    finish_stats(true);
-    throw CapacityError{"match buffer too small"};
+  if (stride && match_extent) *match_extent = stride * n;
+  if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
+  size_t sb = stride ? std::max(sub_batch_, (n + kMaxSub - 1) / kMaxSub) : n;     // row-space matches: one piece
+  const size_t nsub = (n + sb - 1) / sb;
+  for (size_t k = 0; k < nsub; ++k) {
+    const size_t lo = k * sb, cnt = std::min(sb, n - lo);
+    const int par = (int)(k & 1);
+    ev_ = evs_[k];
+    Pipe p;
+    run_device_stages(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr);
+    const uint64_t extent = stride ? stride * cnt : p.nrows;
+    if (!stride) {
+      if (match_extent) *match_extent = extent;
+      if (extent > match_cap) { HIP_CHECK(hipStreamSynchronize(stream_)); throw CapacityError{"match buffer too small"}; }
+    }
+    TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
+    cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
+    cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
+    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
+    k_tail<<<grid_for(cnt, 64), 64, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, p.hits, p.row_off, p.vals,
+                                                  entries, d_res, d_match, stride, stride * lo);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipEventRecord(ev_[7], stream_));
+    HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
+    HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
+    HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
+    if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+    HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   }
-  HIP_CHECK(hipMemcpyAsync(results, d_res, n * sizeof(cfr_result), hipMemcpyDeviceToHost, stream_));
-  if (extent) HIP_CHECK(hipMemcpyAsync(matches, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
-  finish_stats(true);
+  HIP_CHECK(hipStreamSynchronize(copy_stream_));
+  for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+  ev_ = evs_[0];
 }
 
 void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,

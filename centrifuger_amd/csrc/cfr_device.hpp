@@ -12,6 +12,9 @@
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
+//   loc_memo : DERIVED at load time: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
+//              (memo_rate = 1 when n*4 bytes fit the budget).  The LF-walk from row i passes through the same rows
+//              as the reference's, so stopping at a memoised row returns exactly what the full walk would.
 //   sel_rows / sel_vals : sorted selectedSA pairs             (FMIndex.hpp:34)
 #pragma once
 
@@ -33,6 +36,8 @@ struct DevView {            // passed by value to kernels
   const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l); nullptr = off
   uint32_t ftabx_width;     // K (> ftab_width)
   const uint64_t *sampled;
+  const uint32_t *loc_memo; // derived: memo[j / memo_rate] = BackwardToSampledSA(j) for j % memo_rate == 0; nullptr = off
+  uint32_t memo_shift;      // log2(memo_rate)
   const uint64_t *sel_rows, *sel_vals;
   uint64_t sel_cnt;
   uint32_t last_code, ftab_width, sampled_bits, sample_rate;
@@ -118,7 +123,12 @@ class DeviceIndex {
   uint64_t device_bytes_ = 0;
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;
-  hipEvent_t ev_[8] = {};
+  static constexpr size_t kMaxSub = 16;
+  hipEvent_t evs_[kMaxSub][8] = {};
+  hipEvent_t *ev_ = nullptr;
+  hipStream_t copy_stream_ = nullptr;
+  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
+  size_t sub_batch_ = 2500000;
   int num_cus_ = 256, blocks_per_cu_ = 5;
   bool search_v1_ = false;
   void *pinned_ = nullptr;
