@@ -136,6 +136,57 @@ def make_pairs_gpu(torch, cat_d, starts, n_pairs, read_len, seed, device, ins_lo
     return out1, out2
 
 
+def make_long_reads_gpu(torch, cat_d, starts, n_reads, seed, device, len_lo=5000, len_hi=20000, sub_rate=0.04, ins_rate=0.03, del_rate=0.03):
+    """ONT-like reads: U[5k,20k] bp, i.i.d. substitutions / insertions / deletions; flat buffer + offsets, built in HBM."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    starts_d = torch.as_tensor(starts, device=device)
+    lens = starts_d[1:] - starts_d[:-1]
+    comp = torch.full((256,), ord("N"), dtype=torch.uint8, device=device)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    code = torch.zeros(256, dtype=torch.int64, device=device)
+    for i, a in enumerate(b"ACGT"):
+        code[a] = i
+    pieces, piece_lens = [], []
+    chunk = 4096
+    for lo in range(0, n_reads, chunk):
+        m = min(chunk, n_reads - lo)
+        L = torch.randint(len_lo, len_hi + 1, (m,), generator=gen, device=device)
+        gi = torch.randint(0, len(lens), (m,), generator=gen, device=device)
+        pos = (torch.rand(m, generator=gen, device=device, dtype=torch.float64) * (lens[gi] - L).double()).long()
+        off = torch.zeros(m + 1, dtype=torch.int64, device=device)
+        off[1:] = torch.cumsum(L, 0)
+        tot = int(off[-1].item())
+        rid = torch.repeat_interleave(torch.arange(m, device=device), L)
+        within = torch.arange(tot, device=device) - off[rid]
+        rcflag = (torch.rand(m, generator=gen, device=device) < 0.5)[rid]
+        # reverse-strand reads walk the genome segment backwards, complemented
+        src = starts_d[gi][rid] + pos[rid] + torch.where(rcflag, L[rid] - 1 - within, within)
+        r = cat_d[src]
+        r = torch.where(rcflag, comp[r.long()], r)
+        sub = torch.rand(tot, generator=gen, device=device) < sub_rate
+        r = torch.where(sub, acgt[(code[r.long()] + torch.randint(1, 4, (tot,), generator=gen, device=device)) & 3], r)
+        keep = torch.rand(tot, generator=gen, device=device) >= del_rate
+        ins = (torch.rand(tot, generator=gen, device=device) < ins_rate) & keep
+        emit = keep.long() + ins.long()                       # 0 (deleted), 1, or 2 (base + inserted base)
+        out_len = torch.zeros(m, dtype=torch.int64, device=device).index_add_(0, rid, emit)
+        rep = torch.repeat_interleave(torch.arange(tot, device=device), emit)
+        o = r[rep]
+        first = torch.ones_like(rep, dtype=torch.bool)
+        first[1:] = rep[1:] != rep[:-1]
+        rnd = acgt[torch.randint(0, 4, (len(rep),), generator=gen, device=device)]
+        o = torch.where(first, o, rnd)                        # the second copy of a base is the inserted random base
+        pieces.append(o)
+        piece_lens.append(out_len)
+    bases = torch.cat(pieces)
+    ll = torch.cat(piece_lens)
+    offs = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    offs[1:] = torch.cumsum(ll, 0)
+    return bases, offs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,8 +203,9 @@ def main():
     ap.add_argument("--build-threads", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
-    ap.add_argument("--mode", choices=["se", "pe"], default="se",
-                    help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5")
+    ap.add_argument("--mode", choices=["se", "pe", "long"], default="se",
+                    help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
+                         "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")
     ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
     args = ap.parse_args()
 
@@ -191,15 +243,32 @@ def main():
     cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     starts = np.load(os.path.join(cache, "genome_starts.npy"))
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
+    longmode = args.mode == "long"
+    if longmode and args.reads == 10_000_000:
+        args.reads = 200_000
+    if longmode and args.cpu_sample == 2_000_000:
+        args.cpu_sample = 20_000
+    if longmode and args.count_sample == 200_000:
+        args.count_sample = 4_000
     if paired:
         reads_d, reads2_d = make_pairs_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
+    elif longmode:
+        reads_d, offs_d = make_long_reads_gpu(torch, cat_d, starts, args.reads, args.seed + 1000 + rank, device)
+        reads2_d = None
     else:
         reads_d = make_reads_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
         reads2_d = None
     del cat_d
-    offs_d = (torch.arange(args.reads + 1, device=device, dtype=torch.int64) * args.read_len)
+    if not longmode:
+        offs_d = (torch.arange(args.reads + 1, device=device, dtype=torch.int64) * args.read_len)
     torch.cuda.synchronize()
-    total_bases = args.reads * args.read_len
+    offs_h = offs_d.cpu().numpy().astype(np.uint64)
+    total_bases = int(offs_h[-1])
+
+    def sample_of(t, nsel):
+        """first nsel reads of flat device buffer t as (bases, offsets) numpy"""
+        hi = int(offs_h[nsel])
+        return t.reshape(-1)[:hi].cpu().numpy(), offs_h[:nsel + 1].copy()
     res_pin = capi.PinnedArray(args.reads, capi.RESULT_DTYPE)     # cfr_host_alloc: D2H at PCIe rate
     mat_pin = capi.PinnedArray(args.reads * k, capi.MATCH_DTYPE)
     results, matches = res_pin.array, mat_pin.array
@@ -243,7 +312,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), "
-                               f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM",
+                               (f"{args.reads} long reads (5-20 kbp, mean {total_bases/args.reads:.0f} bp) per step per GPU, -k {k}, inputs resident in HBM" if longmode else
+                                f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM"),
                    "index_bp": int(info.n), "reads_per_step_per_gpu": args.reads, "read_len": args.read_len,
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective"},
         "classified_fraction": classified / args.reads,
@@ -254,9 +324,8 @@ def main():
     # ---- roofline of the dominant kernel: algorithmic bytes counted by the C oracle on a sample
     import oracle_lib as ora
     ns = min(args.count_sample, args.reads)
-    sample = reads_d[:ns].cpu().numpy().reshape(-1)
-    sample2 = reads2_d[:ns].cpu().numpy().reshape(-1) if paired else None
-    soffs = (np.arange(ns + 1, dtype=np.uint64) * np.uint64(args.read_len))
+    sample, soffs = sample_of(reads_d, ns)
+    sample2 = sample_of(reads2_d, ns)[0] if paired else None
     o = ora.OracleIndex(prefix, max_result=k)
     threads = min(os.cpu_count() or 1, 64)
     ores, cnt = o.classify(sample, soffs, sample2, soffs if paired else None, threads=threads, counters=True)
@@ -267,10 +336,18 @@ def main():
     bytes_locate = cnt.locate_bytes() / ns
     locate_ms = float(np.mean([s.locate_ms for s in kstats]))
     ach = bytes_search * args.reads / (search_ms / 1e3) / 1e9
+    traffic = None
+    try:   # HBM/fabric bytes from the PMC passes of the same kernel (tools/pmc_passes.sh -> profiles/pmc_latest.json), scaled per read
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_search_chains_v2"]
+        traffic = (pm["fabric_read_bytes_per_read"] + pm["write_bytes_per_read"]) * args.reads
+    except Exception:
+        pass
     out["roofline"] = {
-        "bound": "hbm", "kernel": "k_search_chains", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        "bound": "hbm", "kernel": "k_search_chains_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_read": bytes_search, "kernel_ms": search_ms,
+        "per": "one step = the launches of the step's sub-batches (achieved, traffic and kernel_ms are all summed over them)",
+        "gather_ceiling": "tools/gather_bench: 53-55 G dependent 64-byte record fetches/s on this chip; this kernel issues ~153 fabric requests/read",
         "note": "achieved = reference-algorithm bytes (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, read bytes, 32 B/hit; counted by the "
                 "C oracle on a sample) / kernel time (HIP events on the library stream); the flat occ layout touches far fewer bytes",
         "second_kernel": {"kernel": "k_locate", "algorithmic_bytes_per_read": bytes_locate, "kernel_ms": locate_ms,
@@ -286,7 +363,7 @@ def main():
         from centrifuger_amd import synth
         ncpu = os.cpu_count() or 1
         nb = min(args.cpu_sample, args.reads)
-        rs = synth.ReadSet(reads_d[:nb].cpu().numpy().reshape(-1), (np.arange(nb + 1, dtype=np.uint64) * np.uint64(args.read_len)))
+        rs = synth.ReadSet(*sample_of(reads_d, nb))
         fa = os.path.join(cache, f"sample_{rank}.fa")
         synth.write_fasta(rs, fa)
         one = os.path.join(cache, "one.fa")
@@ -294,7 +371,7 @@ def main():
         files, files_one = ["-u", fa], ["-u", one]
         rs2 = None
         if paired:
-            rs2 = synth.ReadSet(reads2_d[:nb].cpu().numpy().reshape(-1), rs.offsets.copy())
+            rs2 = synth.ReadSet(sample_of(reads2_d, nb)[0], rs.offsets.copy())
             fa2 = os.path.join(cache, f"sample_{rank}_2.fa")
             synth.write_fasta(rs2, fa2)
             one2 = os.path.join(cache, "one_2.fa")
