@@ -214,14 +214,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    # CFR_BENCH_SHARE_GPU=1: every rank uses device 0 and the process group is gloo - only for exercising the
+    # multi-rank code path on a 1-GPU box; the driver's real runs are one rank per GPU over RCCL.
+    share_gpu = os.environ.get("CFR_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="gloo" if share_gpu else "nccl")
 
     from centrifuger_amd import capi
     key = hashlib.md5(f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}".encode()).hexdigest()[:10]
@@ -293,10 +298,8 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from centrifuger_amd import shard
+    elapsed = shard.max_over_ranks(elapsed, dist=dist, device=None if share_gpu else device)   # the job is as slow as its slowest rank
     classified = int((results["n_match"] > 0).sum())
 
     if rank != 0:
@@ -311,7 +314,7 @@ def main():
         "metric": "classified reads/sec (150 bp)", "value": value, "unit": "read pairs/s" if paired else "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), "
+        "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), " +
                                (f"{args.reads} long reads (5-20 kbp, mean {total_bases/args.reads:.0f} bp) per step per GPU, -k {k}, inputs resident in HBM" if longmode else
                                 f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM"),
                    "index_bp": int(info.n), "reads_per_step_per_gpu": args.reads, "read_len": args.read_len,
