@@ -36,8 +36,10 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def build_index(args, cache):
-    """Index generation is OUT of the timed path.  Uses the reference's own centrifuger-build (oracle/_ref)."""
+def build_index(args, cache, device=None):
+    """Index generation is OUT of the timed path.  --builder own: centrifuger_amd/indexbuild.py (suffix array by
+    prefix doubling with torch sorts in HBM, writes the same .cfr fields as the reference's builder, see
+    tests/test_indexbuild.py); --builder reference: the reference's own centrifuger-build (oracle/_ref)."""
     from centrifuger_amd import synth
     prefix = os.path.join(cache, "idx")
     if os.path.exists(prefix + ".done"):
@@ -45,20 +47,25 @@ def build_index(args, cache):
     os.makedirs(cache, exist_ok=True)
     t0 = time.time()
     g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed)
-    synth.write_reference_inputs(g, cache)
     np.save(os.path.join(cache, "genome_cat.npy"), np.concatenate(g.seqs))
     np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum([len(s) for s in g.seqs])]).astype(np.int64))
-    log(f"genomes: {g.total_len/1e6:.0f} Mbp generated+written in {time.time()-t0:.1f}s")
+    log(f"genomes: {g.total_len/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
     t0 = time.time()
-    builder = os.path.join(ROOT, "oracle", "_ref", "centrifuger-build")
-    if not os.path.exists(builder):
-        raise SystemExit("oracle/_ref/centrifuger-build missing: run __graft_entry__.build() where /root/reference exists")
-    subprocess.run([builder, "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "ref.fa"),
-                    "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
-                    "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix],
-                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    log(f"index built by reference centrifuger-build in {time.time()-t0:.1f}s")
-    os.remove(os.path.join(cache, "ref.fa"))
+    if args.builder == "own":
+        from centrifuger_amd import indexbuild
+        indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=device, log=log)
+        log(f"index built by centrifuger_amd.indexbuild in {time.time()-t0:.1f}s")
+    else:
+        synth.write_reference_inputs(g, cache)
+        builder = os.path.join(ROOT, "oracle", "_ref", "centrifuger-build")
+        if not os.path.exists(builder):
+            raise SystemExit("oracle/_ref/centrifuger-build missing: run __graft_entry__.build() where /root/reference exists")
+        subprocess.run([builder, "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "ref.fa"),
+                        "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
+                        "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        log(f"index built by reference centrifuger-build in {time.time()-t0:.1f}s")
+        os.remove(os.path.join(cache, "ref.fa"))
     open(prefix + ".done", "w").close()
     return prefix
 
@@ -202,6 +209,7 @@ def main():
     ap.add_argument("--count-sample", type=int, default=200_000, help="reads the C oracle counts operations on")
     ap.add_argument("--build-threads", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--builder", choices=["own", "reference"], default="own", help="who writes the .cfr index (outside the timed path)")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
     ap.add_argument("--mode", choices=["se", "pe", "long"], default="se",
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
@@ -229,10 +237,11 @@ def main():
         dist.init_process_group(backend="gloo" if share_gpu else "nccl")
 
     from centrifuger_amd import capi
-    key = hashlib.md5(f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}".encode()).hexdigest()[:10]
+    key = hashlib.md5(f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}".encode()).hexdigest()[:10]
     cache = os.path.join(args.cache, key)
     if rank == 0:
-        prefix = build_index(args, cache)
+        prefix = build_index(args, cache, device)
+        torch.cuda.empty_cache()
     if dist is not None:
         dist.barrier()
     prefix = os.path.join(cache, "idx")
