@@ -445,3 +445,71 @@ def write_taxonomy(path, names, taxids, nodes, tax_names):
         for nm in names:
             s = nm.encode()
             f.write(struct.pack("<Q", len(s)) + s)
+
+
+# ----------------------------------------------------------------------------------------------- command line
+def read_fasta(paths):
+    """[(name, np.uint8 ACGT-only sequence)]: everything that is not an upper-case A,C,G,T is dropped, like
+    SequenceCompactor::Compact (SequenceCompactor.hpp:59-84; no capitalisation, no replacement)."""
+    import gzip
+    keep = np.zeros(256, dtype=bool)
+    for ch in ACGT:
+        keep[ch] = True
+    out = []
+    for p in paths:
+        opener = gzip.open if p.endswith(".gz") else open
+        with opener(p, "rb") as f:
+            data = f.read()
+        for rec in data.split(b">")[1:]:
+            head, _, body = rec.partition(b"\n")
+            arr = np.frombuffer(body, dtype=np.uint8)
+            out.append((head.split()[0].decode(), arr[keep[arr]].copy()))
+    return out
+
+
+def read_taxonomy_files(nodes_path, names_path, map_path):
+    nodes, names, seqmap = [], [], []
+    for line in open(nodes_path):
+        if not line.strip() or line.startswith("#"):
+            continue
+        f = [x.strip() for x in line.split("|")]
+        nodes.append((int(f[0]), int(f[1]), f[2]))
+    for line in open(names_path):
+        if "scientific name" not in line:
+            continue
+        f = [x.strip() for x in line.split("|")]
+        names.append((int(f[0]), f[1]))
+    for line in open(map_path):
+        if not line.strip() or line.startswith("#"):
+            continue
+        a, b = line.split()[:2]
+        seqmap.append((a, int(b)))
+    return nodes, names, seqmap
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m centrifuger_amd.indexbuild",
+                                 description="write a Centrifuger .cfr index (subset of centrifuger-build's options)")
+    ap.add_argument("-r", action="append", required=True, help="reference FASTA (repeatable)")
+    ap.add_argument("--taxonomy-tree", required=True)
+    ap.add_argument("--name-table", required=True)
+    ap.add_argument("--conversion-table", required=True)
+    ap.add_argument("-o", default="centrifuger")
+    ap.add_argument("--ftabchars", type=int, default=10)
+    ap.add_argument("--offrate", type=int, default=4)
+    ap.add_argument("--rbbwt-b", type=int, default=0)
+    a = ap.parse_args(argv)
+    nodes, names, seqmap = read_taxonomy_files(a.taxonomy_tree, a.name_table, a.conversion_table)
+    seqs = dict(read_fasta(a.r))
+    order = [(nm, tid) for nm, tid in seqmap if nm in seqs and len(seqs[nm]) >= a.ftabchars + 1]
+    if not order:
+        raise SystemExit("no sequence of the conversion table found in the FASTA input")
+    if [nm for nm, _ in order] != [nm for nm, _ in seqmap]:
+        raise SystemExit("every sequence of the conversion table must be present (and longer than ftabchars) in this writer")
+    build_index([nm for nm, _ in order], [t for _, t in order], [seqs[nm] for nm, _ in order], nodes, names, a.o,
+                ftab_chars=a.ftabchars, offrate=a.offrate, rbbwt_b=a.rbbwt_b, log=lambda m: print("[indexbuild]", m))
+
+
+if __name__ == "__main__":
+    main()
