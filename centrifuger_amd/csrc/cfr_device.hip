@@ -173,6 +173,38 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       view_.ftabx_width = K;
     }
   }
+  // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
+  view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
+  {
+    bool want = h.n >= 64 && h.n < 0xfffffff0ull;
+    if (const char *e = getenv("CFR_TEXT_MODE")) want = want && atoi(e) != 0;
+    if (want) {
+      uint2 *la = nullptr, *lb = nullptr;
+      HIP_CHECK(hipMalloc((void **)&la, h.n * sizeof(uint2)));
+      HIP_CHECK(hipMalloc((void **)&lb, h.n * sizeof(uint2)));
+      const unsigned g = (unsigned)std::min<uint64_t>((h.n + 255) / 256, 1u << 20);
+      k_lf_init<<<g, 256, 0, stream_>>>(view_, la);
+      for (uint64_t span = 1; span < h.n; span <<= 1) {
+        k_lf_jump<<<g, 256, 0, stream_>>>(h.n, la, lb);
+        std::swap(la, lb);
+      }
+      HIP_CHECK(hipGetLastError());
+      uint32_t *d_sa = dev_alloc<uint32_t>(h.n), *d_isa = dev_alloc<uint32_t>(h.n);
+      const uint64_t twords = (h.n + 31) / 32 + 2;
+      uint64_t *d_text = dev_alloc<uint64_t>(twords);
+      HIP_CHECK(hipMemsetAsync(d_text, 0, twords * 8, stream_));
+      k_text_fill<<<g, 256, 0, stream_>>>(view_, la, d_sa, d_isa, (unsigned long long *)d_text);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      HIP_CHECK(hipFree(la));
+      HIP_CHECK(hipFree(lb));
+      view_.sa32 = d_sa; view_.isa32 = d_isa; view_.text2 = d_text;
+      uint32_t log4n = 0;
+      while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
+      view_.text_min_l = log4n + 2;                       // random matches rarely get past log4(n) characters
+      if (const char *e = getenv("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
+    }
+  }
   // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
   view_.loc_memo = nullptr;
   view_.memo_shift = 0;

@@ -12,6 +12,10 @@
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
+//   sa32/isa32/text2 : DERIVED at load time (list ranking over the LF permutation, k_lf_init/k_lf_jump/k_text_fill):
+//              SA[row], ISA[pos] and the 2-bit text.  A BWT range of <= 4 rows is then extended by comparing the read
+//              with the text 32 bases per step (the rows' suffix positions move in lock step), instead of one LF
+//              step per base; the range is mapped back with ISA when the search ends.
 //   loc_memo : DERIVED at load time: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
 //              (memo_rate = 1 when n*4 bytes fit the budget).  The LF-walk from row i passes through the same rows
 //              as the reference's, so stopping at a memoised row returns exactly what the full walk would.
@@ -38,6 +42,10 @@ struct DevView {            // passed by value to kernels
   const uint64_t *sampled;
   const uint32_t *loc_memo; // derived: memo[j / memo_rate] = BackwardToSampledSA(j) for j % memo_rate == 0; nullptr = off
   uint32_t memo_shift;      // log2(memo_rate)
+  // derived text-mode tables (n < 2^32): suffix array, its inverse, and the 2-bit text; nullptr = off
+  const uint32_t *sa32, *isa32;
+  const uint64_t *text2;    // symbol p at bits 2(p%32) of word p/32
+  uint32_t text_min_l;      // a search switches to text comparison once it has matched this many characters
   const uint64_t *sel_rows, *sel_vals;
   uint64_t sel_cnt;
   uint32_t last_code, ftab_width, sampled_bits, sample_rate;
@@ -129,7 +137,7 @@ class DeviceIndex {
   hipStream_t copy_stream_ = nullptr;
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
   size_t sub_batch_ = 2500000;
-  int num_cus_ = 256, blocks_per_cu_ = 5;
+  int num_cus_ = 256, blocks_per_cu_ = 4;
   bool search_v1_ = false;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
