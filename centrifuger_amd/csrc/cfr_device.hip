@@ -189,10 +189,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
         std::swap(la, lb);
       }
       HIP_CHECK(hipGetLastError());
-      uint32_t *d_sa = dev_alloc<uint32_t>(h.n), *d_isa = dev_alloc<uint32_t>(h.n);
-      const uint64_t twords = (h.n + 31) / 32 + 2;
-      uint64_t *d_text = dev_alloc<uint64_t>(twords);
-      HIP_CHECK(hipMemsetAsync(d_text, 0, twords * 8, stream_));
+      uint32_t *d_sa = dev_alloc<uint32_t>(h.n + 4), *d_isa = dev_alloc<uint32_t>(h.n + 4);   // +4: slots are read 8 bytes at a time
+      const uint64_t twords = (h.n + 31) / 32 + 4;
+      uint64_t *d_text = dev_alloc<uint64_t>(twords) + 1;                                      // one pad word in front (see k_search_chains_v2)
+      HIP_CHECK(hipMemsetAsync(d_text - 1, 0, twords * 8, stream_));
+      HIP_CHECK(hipMemsetAsync(d_sa + h.n, 0, 16, stream_));
+      HIP_CHECK(hipMemsetAsync(d_isa + h.n, 0, 16, stream_));
       k_text_fill<<<g, 256, 0, stream_>>>(view_, la, d_sa, d_isa, (unsigned long long *)d_text);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
@@ -364,8 +366,15 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   } else {
     // persistent grid: every lane walks chains gid, gid + T, ... (T = resident lanes), see k_search_chains_v2
     const unsigned blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * blocks_per_cu_));
-    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, total1, total2, hit_off, raw, chain_cnt);
-    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, total1, 0, hit_off, raw, chain_cnt);
+    SearchView sv;
+    sv.n = view_.n; sv.first_isa = view_.first_isa;
+    for (int c = 0; c < 4; ++c) sv.C[c] = view_.C[c];
+    sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
+    sv.sa32 = view_.sa32; sv.isa32 = view_.isa32;
+    sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
+    sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
+    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, d_b1, d_o1, d_b2, d_o2, n, total1, total2, hit_off, raw, chain_cnt);
+    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, d_b1, d_o1, nullptr, nullptr, n, total1, 0, hit_off, raw, chain_cnt);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));

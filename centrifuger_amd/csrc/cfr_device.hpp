@@ -137,7 +137,7 @@ class DeviceIndex {
   hipStream_t copy_stream_ = nullptr;
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
   size_t sub_batch_ = 2500000;
-  int num_cus_ = 256, blocks_per_cu_ = 4;
+  int num_cus_ = 256, blocks_per_cu_ = 5;
   bool search_v1_ = false;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
