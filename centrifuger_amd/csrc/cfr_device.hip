@@ -189,12 +189,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
         std::swap(la, lb);
       }
       HIP_CHECK(hipGetLastError());
-      uint32_t *d_sa = dev_alloc<uint32_t>(h.n + 4), *d_isa = dev_alloc<uint32_t>(h.n + 4);   // +4: slots are read 8 bytes at a time
+      uint32_t *d_sa = dev_alloc<uint32_t>(h.n + 8), *d_isa = dev_alloc<uint32_t>(h.n + 8);   // +8: slots are read 16 bytes at a time
       const uint64_t twords = (h.n + 31) / 32 + 4;
       uint64_t *d_text = dev_alloc<uint64_t>(twords) + 1;                                      // one pad word in front (see k_search_chains_v2)
       HIP_CHECK(hipMemsetAsync(d_text - 1, 0, twords * 8, stream_));
-      HIP_CHECK(hipMemsetAsync(d_sa + h.n, 0, 16, stream_));
-      HIP_CHECK(hipMemsetAsync(d_isa + h.n, 0, 16, stream_));
+      HIP_CHECK(hipMemsetAsync(d_sa + h.n, 0, 32, stream_));
+      HIP_CHECK(hipMemsetAsync(d_isa + h.n, 0, 32, stream_));
       k_text_fill<<<g, 256, 0, stream_>>>(view_, la, d_sa, d_isa, (unsigned long long *)d_text);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
