@@ -23,7 +23,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -373,8 +373,9 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
     sv.sa32 = view_.sa32; sv.isa32 = view_.isa32;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
-    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, d_b1, d_o1, d_b2, d_o2, n, total1, total2, hit_off, raw, chain_cnt);
-    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, d_b1, d_o1, nullptr, nullptr, n, total1, 0, hit_off, raw, chain_cnt);
+    // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
+    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
+    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
@@ -425,6 +426,21 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   last_stats.n_rows += nrows;
 }
 
+// 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
+void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2) {
+  nblk1_ = (total1 + 15) / 16;
+  packed1_ = (uint64_t *)scratch(S_PACK1, (nblk1_ + 2) * 8);
+  if (nblk1_) k_pack_reads<<<grid_for(nblk1_), kBlock, 0, stream_>>>(d_b1, total1, nblk1_, packed1_);
+  nblk2_ = 0;
+  packed2_ = nullptr;
+  if (d_b2) {
+    nblk2_ = (total2 + 15) / 16;
+    packed2_ = (uint64_t *)scratch(S_PACK2, (nblk2_ + 2) * 8);
+    if (nblk2_) k_pack_reads<<<grid_for(nblk2_), kBlock, 0, stream_>>>(d_b2, total2, nblk2_, packed2_);
+  }
+  HIP_CHECK(hipGetLastError());
+}
+
 void DeviceIndex::finish_stats(bool want_rows) {
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev_[a], ev_[b]); return t; };
   last_stats.pack_ms += ms(0, 1);
@@ -447,6 +463,7 @@ void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uin
   last_stats = cfr_batch_stats{};
   if (n == 0) return;
   Pipe p;
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
   run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, want_rows, p, &out.hit_begin);
   out.hits.resize(p.nhits);
   if (p.nhits) HIP_CHECK(hipMemcpyAsync(out.hits.data(), p.hits, p.nhits * sizeof(cfr_hit), hipMemcpyDeviceToHost, stream_));
@@ -489,6 +506,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
   size_t sb = stride ? std::max(sub_batch_, (n + kMaxSub - 1) / kMaxSub) : n;     // row-space matches: one piece
   const size_t nsub = (n + sb - 1) / sb;
   for (size_t k = 0; k < nsub; ++k) {

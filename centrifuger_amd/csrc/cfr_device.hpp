@@ -122,6 +122,7 @@ class DeviceIndex {
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
+  void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2);
 
   const HostIndex *host_;
   int device_;
@@ -137,7 +138,9 @@ class DeviceIndex {
   hipStream_t copy_stream_ = nullptr;
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
   size_t sub_batch_ = 2500000;
-  int num_cus_ = 256, blocks_per_cu_ = 5;
+  int num_cus_ = 256, blocks_per_cu_ = 7;
+  uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
+  uint64_t nblk1_ = 0, nblk2_ = 0;
   bool search_v1_ = false;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
