@@ -524,7 +524,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
     cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
     if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
-    k_tail<<<grid_for(cnt, 64), 64, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, p.hits, p.row_off, p.vals,
+    k_tail<<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, p.hits, p.row_off, p.vals,
                                                   entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev_[7], stream_));
