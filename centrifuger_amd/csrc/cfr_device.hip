@@ -163,7 +163,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     uint32_t K = std::min<uint32_t>(14, std::max<uint32_t>(view_.ftab_width + 2, log4n + 1));
     if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
-    if (K > view_.ftab_width && view_.ftab_width > 0) {
+    if (K > view_.ftab_width && view_.ftab_width > 0) try {
       const uint64_t entries = 1ull << (2 * K);
       uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2);
       k_build_ftabx<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, K, d_tab);
@@ -171,17 +171,17 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       HIP_CHECK(hipStreamSynchronize(stream_));
       view_.ftabx = d_tab;
       view_.ftabx_width = K;
-    }
+    } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; }   // optional table: run without it
   }
   // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
   view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
     bool want = h.n >= 64 && h.n < 0xfffffff0ull;
     if (const char *e = getenv("CFR_TEXT_MODE")) want = want && atoi(e) != 0;
-    if (want) {
+    if (want) try {
       uint2 *la = nullptr, *lb = nullptr;
       HIP_CHECK(hipMalloc((void **)&la, h.n * sizeof(uint2)));
-      HIP_CHECK(hipMalloc((void **)&lb, h.n * sizeof(uint2)));
+      if (hipMalloc((void **)&lb, h.n * sizeof(uint2)) != hipSuccess) { (void)hipFree(la); throw HipError{"no room for the list-ranking buffers", -3}; }
       const unsigned g = (unsigned)std::min<uint64_t>((h.n + 255) / 256, 1u << 20);
       k_lf_init<<<g, 256, 0, stream_>>>(view_, la);
       for (uint64_t span = 1; span < h.n; span <<= 1) {
@@ -205,7 +205,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
       view_.text_min_l = log4n + 2;                       // random matches rarely get past log4(n) characters
       if (const char *e = getenv("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
-    }
+    } catch (const HipError &) { (void)hipGetLastError(); view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; }   // optional tables
   }
   // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
   view_.loc_memo = nullptr;
@@ -218,7 +218,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     const bool fits32 = h.sampled_bits <= 32 && max_val <= 0xffffffffull;
     uint32_t shift = 0;
     while (shift < 8 && (double)((h.n >> shift) + 1) * 4.0 > budget_gb * 1e9) ++shift;
-    if (budget_gb > 0 && fits32 && (1u << shift) < (uint32_t)h.sample_rate) {
+    if (budget_gb > 0 && fits32 && (1u << shift) < (uint32_t)h.sample_rate) try {
       const uint64_t entries = ((h.n - 1) >> shift) + 1;
       uint32_t *d_memo = dev_alloc<uint32_t>(entries);
       k_build_loc_memo<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, shift, entries, d_memo);
@@ -226,7 +226,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       HIP_CHECK(hipStreamSynchronize(stream_));
       view_.loc_memo = d_memo;
       view_.memo_shift = shift;
-    }
+    } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
   }
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;

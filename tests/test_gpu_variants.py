@@ -1,0 +1,32 @@
+"""Every switchable code path of the device pipeline must give the same bits: the parity suite is re-run in a
+subprocess under each combination of the CFR_* switches (derived tables on/off, v1/v2 search kernel, tiny
+sub-batches, sparse locate memo).  -m gpu."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "search_v1": {"CFR_SEARCH_V1": "1"},
+    "no_derived_tables": {"CFR_FTABX_WIDTH": "0", "CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0"},
+    "text_mode_early": {"CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
+    "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003"},
+    "wide_ftabx_one_block_per_cu": {"CFR_FTABX_WIDTH": "12", "CFR_BLOCKS_PER_CU": "1"},
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_parity_suite_under_switches(name):
+    env = dict(os.environ)
+    env.update(VARIANTS[name])
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-k", "tsv or hit_lists or backward_search or degenerate or fresh_index"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0, f"{name} {VARIANTS[name]}:\n{tail}"
+    assert " passed" in tail
