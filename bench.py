@@ -412,6 +412,16 @@ def main():
         out["parity"] = {"reads": nb, "tsv_identical_to_reference": gpu_tsv == ref_tsv,
                          "md5": hashlib.md5(gpu_tsv).hexdigest()}
         out["speedup_vs_cpu"] = value / world / cpu_rate
+        # ---- end-to-end wall clock of the drop-in command line on the same file (parse + dust + device + TSV, index load included)
+        cli = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
+        if os.path.exists(cli):
+            t0 = time.time()
+            cli_tsv = subprocess.run([cli, "-x", prefix, "-t", str(min(ncpu, 64)), "-k", str(k)] + files, check=True,
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            t_cli = time.time() - t0
+            out["e2e_cli"] = {"reads": nb, "seconds": t_cli, "reference_seconds": t_full, "speedup": t_full / t_cli,
+                              "tsv_identical_to_reference": cli_tsv == ref_tsv,
+                              "note": "wall clock of `centrifuger -x idx ...` on the sample file, index load / device image included on both sides"}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
