@@ -74,6 +74,53 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   if (const char *e = getenv("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
 
+  bool layout_rb = false;
+  if (const char *e = getenv("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
+  memset(&view_.rb, 0, sizeof(view_.rb));
+  uint64_t *d_occ = nullptr;
+  if (layout_rb) {
+    // ---- run-block image: the 7 bitvectors as rank lines (cfr_device.hpp); no flat occ array at all
+    auto lines_of = [&](const RawBitvector &bv) -> RankLines {
+      const uint64_t nl = bv.n / 448 + 2;
+      std::vector<uint64_t> L(nl * 8, 0);
+      uint64_t ones = 0;
+      for (uint64_t k = 0; k < nl; ++k) {
+        L[k * 8] = ones;
+        for (int wq = 0; wq < 7; ++wq) {
+          // payload word wq of line k = bits [448k + 64wq, +64) of the vector (unaligned gather from the 64-bit words)
+          const uint64_t bit = k * 448 + (uint64_t)wq * 64;
+          uint64_t w = 0;
+          if (bit < bv.n) {
+            const uint64_t wi = bit >> 6, sh = bit & 63;
+            w = bv.bits[wi] >> sh;
+            if (sh && wi + 1 < bv.bits.size()) w |= bv.bits[wi + 1] << (64 - sh);
+            if (bit + 64 > bv.n) w &= (1ull << (bv.n - bit)) - 1;      // nothing beyond the last bit
+          }
+          L[k * 8 + 1 + wq] = w;
+          ones += (uint64_t)__builtin_popcountll(w);
+        }
+      }
+      return RankLines{upload(L), bv.n};
+    };
+    view_.rb.use = lines_of(h.use_run_block);
+    for (int k = 0; k < 3; ++k) {
+      view_.rb.plain[k] = h.wavelet_seq.node_cnt ? lines_of(h.wavelet_seq.node[k]) : RankLines{nullptr, 0};
+      view_.rb.runs[k] = h.run_block_seq.node_cnt ? lines_of(h.run_block_seq.node[k]) : RankLines{nullptr, 0};
+    }
+    // children order: node 1 = codes 0x, node 2 = codes 1x (checked by the parser)
+    if (h.wavelet_seq.node_cnt && h.wavelet_seq.children[0][0] == 2) std::swap(view_.rb.plain[1], view_.rb.plain[2]);
+    if (h.run_block_seq.node_cnt && h.run_block_seq.children[0][0] == 2) std::swap(view_.rb.runs[1], view_.rb.runs[2]);
+    view_.rb.b = h.b;
+    view_.rb.block_cnt = h.block_cnt;
+    view_.rb.filter_rate = (uint32_t)h.selected_filter_rate;
+    if (!h.selected_rows.empty()) {
+      std::vector<uint64_t> filt(((h.n + view_.rb.filter_rate - 1) / view_.rb.filter_rate + 63) / 64 + 1, 0);
+      for (uint64_t r : h.selected_rows) { const uint64_t fb = r / view_.rb.filter_rate; filt[fb >> 6] |= 1ull << (fb & 63); }
+      view_.rb.sel_filter = upload(filt);
+    }
+    view_.rb.enabled = 1;
+    search_v1_ = true;                 // the state-machine kernel reads the flat occ records directly
+  } else {
   // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp)
   const uint64_t nrec = (h.n >> 7) + 2;
   std::vector<uint64_t> occ(nrec * 8, 0);
@@ -110,9 +157,9 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     run[3] += c3; run[2] += c2; run[1] += c1; run[0] += 64 - c3 - c2 - c1;
   }
   for (uint64_t r : h.selected_rows) occ[(r >> 7) * 8] |= kSelFlag;
-  uint64_t *d_occ = dev_alloc<uint64_t>(occ.size());
+  d_occ = dev_alloc<uint64_t>(occ.size());
   HIP_CHECK(hipMemcpy(d_occ, occ.data(), occ.size() * 8, hipMemcpyHostToDevice));
-  std::vector<uint64_t>().swap(occ);
+  }
 
   uint64_t *d_ftab = dev_alloc<uint64_t>(h.ftab.size());
   if (!h.ftab.empty()) HIP_CHECK(hipMemcpy(d_ftab, h.ftab.data(), h.ftab.size() * 8, hipMemcpyHostToDevice));
@@ -176,7 +223,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
   view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
-    bool want = h.n >= 64 && h.n < 0xfffffff0ull;
+    bool want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb;
     if (const char *e = getenv("CFR_TEXT_MODE")) want = want && atoi(e) != 0;
     if (want) try {
       uint2 *la = nullptr, *lb = nullptr;

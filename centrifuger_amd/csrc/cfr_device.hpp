@@ -32,9 +32,24 @@
 
 namespace cfr {
 
+// Run-block image (CFR_LAYOUT=rb): the reference's own components kept compressed in HBM.  Every bitvector
+// (useRunBlock; 3 wavelet nodes of the non-run symbols; 3 of the run symbols) is stored as 64-byte "rank lines":
+// u64 #ones before the line + 7 payload words (448 bits), so one bit-rank / bit-access = one line
+// (DS_Rank9 needs the counter pair and the word from two arrays).
+struct RankLines { const uint64_t *lines; uint64_t nbits; };
+struct RbView {
+  RankLines use, plain[3], runs[3];
+  uint64_t b;                        // run-block size (Sequence_RunBlock::_b)
+  uint64_t block_cnt;
+  const uint64_t *sel_filter;        // 1 bit per filter_rate rows (FMIndex.hpp:35-36, 166-176)
+  uint32_t filter_rate;
+  uint32_t enabled;                  // 0: flat occ image
+};
+
 struct DevView {            // passed by value to kernels
   uint64_t n, first_isa, adjusted_sa0;
   uint64_t C[5];
+  RbView rb;                // run-block image (alternative to occ)
   const uint64_t *occ;      // 8 u64 per record
   const uint64_t *ftab;     // 2 u64 per entry
   const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l); nullptr = off

@@ -17,6 +17,9 @@ VARIANTS = {
     "text_mode_early": {"CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003"},
     "wide_ftabx_one_block_per_cu": {"CFR_FTABX_WIDTH": "12", "CFR_BLOCKS_PER_CU": "1"},
+    # the reference's own compressed components in HBM (rank lines, wavelet trees, run-block rank): whole parity file
+    "run_block_layout": {"CFR_LAYOUT": "rb"},
+    "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
 
@@ -24,8 +27,8 @@ VARIANTS = {
 def test_parity_suite_under_switches(name):
     env = dict(os.environ)
     env.update(VARIANTS[name])
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
-                        "-k", "tsv or hit_lists or backward_search or degenerate or fresh_index"],
+    select = [] if name.startswith("run_block") else ["-k", "tsv or hit_lists or backward_search or degenerate or fresh_index"]
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"] + select,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, f"{name} {VARIANTS[name]}:\n{tail}"
