@@ -204,10 +204,14 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.ftabx = nullptr;
   view_.ftabx_width = 0;
   {
-    // auto: about one K-mer per text position, at least 2 characters wider than the on-disk ftab, at most 14 (4.3 GB)
+    // auto: about one K-mer per text position (an unmatched strand then ends inside the lookup), at least 2 characters
+    // wider than the on-disk ftab, at most 16 (68 GB) and never more than a quarter of the free HBM
     uint32_t log4n = 0;
     while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
-    uint32_t K = std::min<uint32_t>(14, std::max<uint32_t>(view_.ftab_width + 2, log4n + 1));
+    uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 1));
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
     if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
     if (K > view_.ftab_width && view_.ftab_width > 0) try {

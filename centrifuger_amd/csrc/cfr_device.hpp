@@ -8,7 +8,7 @@
 //              => FMIndex::Rank(c, p) / Sequence::Access(p) touch exactly ONE 64-byte record:
 //                 8 B (mid[c]) + 16 B (the half that holds symbol p).
 //   ftab     : (start, count) u64 pairs, 4^w entries          (FMIndex.hpp:27)
-//   ftabx    : DERIVED at load time, never on disk: for every K-mer (K = 12..16 > w) the exact state
+//   ftabx    : DERIVED at load time, never on disk: for every K-mer (K = log4(n)+1, at most 16, > w) the exact state
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
