@@ -371,7 +371,7 @@ def main():
 
     # ---- CPU baseline: the real reference binary on this box's host cores + TSV parity on the sample
     refbin = os.path.join(ROOT, "oracle", "_ref", "centrifuger")
-    if not args.no_cpu_baseline and os.path.exists(refbin):
+    if not args.no_cpu_baseline and os.path.exists(refbin) and world == 1:    # reported baseline: rank 0 at N = 1 only
         from centrifuger_amd import synth
         ncpu = os.cpu_count() or 1
         nb = min(args.cpu_sample, args.reads)
