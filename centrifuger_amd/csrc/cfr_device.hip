@@ -23,7 +23,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -72,6 +72,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = getenv("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
+  if (const char *e = getenv("CFR_FUSED_TAIL")) fused_tail_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
 
   bool layout_rb = false;
@@ -386,7 +387,8 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 // search -> adjust/select -> compact -> (enumerate rows -> locate).  Two small D2H syncs (hit and row totals)
 // size the dense arrays; everything else stays on the device.
 void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                    uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host) {
+                                    uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
+                                    bool fused) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -431,9 +433,28 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
   HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, stream_));
-  if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows);
-  else k_adjust_select<2><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows);
+  uint64_t *read_rows = fused ? (uint64_t *)scratch(S_READROWS, (n + 1) * 8) : nullptr;
+  if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
+  else k_adjust_select<2><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
   HIP_CHECK(hipGetLastError());
+  if (fused) {
+    // per-read row bases; one 8-byte sync sizes the tail's scratch
+    uint64_t *read_row_off = (uint64_t *)scratch(S_READROWOFF, (n + 1) * 8);
+    HIP_CHECK(hipMemsetAsync(read_rows + n, 0, 8, stream_));
+    exclusive_scan(tmp, tmp_bytes, read_rows, read_row_off, n, stream_);
+    HIP_CHECK(hipEventRecord(ev_[3], stream_));
+    HIP_CHECK(hipMemcpyAsync(&totals[1], read_row_off + n, 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    const uint64_t nrows_f = totals[1];
+    uint64_t *vals_f = (uint64_t *)scratch(S_ROWVALS, (nrows_f + 1) * 8);
+    HIP_CHECK(hipEventRecord(ev_[4], stream_));
+    HIP_CHECK(hipEventRecord(ev_[5], stream_));
+    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f};
+    last_stats.n_chains += nchains;
+    last_stats.n_rows += nrows_f;
+    return;
+  }
   exclusive_scan(tmp, tmp_bytes, fin_cnt, fin_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[3], stream_));
   HIP_CHECK(hipMemcpyAsync(&totals[0], fin_off + n, 8, hipMemcpyDeviceToHost, stream_));
@@ -565,7 +586,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     const int par = (int)(k & 1);
     ev_ = evs_[k];
     Pipe p;
-    run_device_stages(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr);
+    const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;
+    run_device_stages(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr, fused);
     const uint64_t extent = stride ? stride * cnt : p.nrows;
     if (!stride) {
       if (match_extent) *match_extent = extent;
@@ -575,8 +597,10 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
     cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
     if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
-    k_tail<<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, p.hits, p.row_off, p.vals,
-                                                  entries, d_res, d_match, stride, stride * lo);
+    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
+                                                                  p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
+    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
+                                                              p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev_[7], stream_));
     HIP_CHECK(hipEventRecord(tail_done_[par], stream_));

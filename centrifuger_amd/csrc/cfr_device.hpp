@@ -133,7 +133,8 @@ class DeviceIndex {
   // device stages shared by run_batch / classify_device; returns (nhits, nrows) and leaves device pointers in p_
   struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; };
   void run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                         uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host);
+                         uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
+                         bool fused = false);
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
@@ -156,7 +157,7 @@ class DeviceIndex {
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
-  bool search_v1_ = false;
+  bool search_v1_ = false, fused_tail_ = true;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
 };
