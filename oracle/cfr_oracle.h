@@ -12,7 +12,7 @@
  * Parity pinning: validated against the REAL reference compiled in the dev container
  * (oracle/_ref, built by oracle/Makefile from /root/reference) — TSV byte-identity on
  * synthetic read sets and exhaustive Rank/Access/BackwardSearch/locate vectors
- * (tests/test_oracle_vs_ref.py, fixtures under tests/golden/).
+ * (live: tests/test_oracle_vs_ref.py; committed fixtures: tests/test_oracle_golden.py + tests/golden/).
  */
 #ifndef CFR_ORACLE_H
 #define CFR_ORACLE_H

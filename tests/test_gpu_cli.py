@@ -53,11 +53,3 @@ def test_cli_read_dumps_match_reference(golden_dir, tmp_path):
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for name in ("un.fq.gz", "cl.fq.gz", "pun_1.fq.gz", "pun_2.fq.gz", "pcl_1.fq.gz", "pcl_2.fq.gz"):
         assert gzip.open(tmp_path / f"gpu_{name}").read() == gzip.open(tmp_path / f"ref_{name}").read(), name
-
-
-def test_cli_rejects_out_of_scope_options_and_missing_index(golden_dir):
-    r = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq"), "--merge-readpair"],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"not available in this build" in r.stderr
-    r = subprocess.run([CLI, "-x", "/nonexistent/idx", "-u", os.path.join(golden_dir, "se.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"loading the index" in r.stderr

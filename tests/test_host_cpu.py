@@ -161,3 +161,22 @@ def test_host_tail_from_oracle_hits_reproduces_reference_tsv(case, golden_dir):
                                               np.array(row_vals, dtype=np.uint64), qlen, threads=3)
     out = capi.tsv_header() + b"".join(idx.format_tsv(ids[i], results[i], matches) for i in range(len(ids)))
     assert out == open(os.path.join(GOLDEN, "tsv", case + ".tsv"), "rb").read()
+
+
+def test_cli_rejects_out_of_scope_options_and_missing_index(golden_dir):
+    """The drop-in command line refuses options outside the path and reports a missing index as an error, both before
+    any device work (so this runs without a GPU)."""
+    import subprocess
+    cli = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    r = subprocess.run([cli, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq"), "--merge-readpair"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"not available in this build" in r.stderr
+    r = subprocess.run([cli, "-x", "/nonexistent/idx", "-u", os.path.join(golden_dir, "se.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"loading the index" in r.stderr
+    r = subprocess.run([cli], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and b"-x FILE: index prefix" in r.stderr       # no arguments: usage, exit 0 (like the reference's CI smoke)
+    if capi.device_count() == 0:
+        r = subprocess.run([cli, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode != 0 and b"no CPU fallback" in r.stderr
