@@ -74,6 +74,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   if (const char *e = getenv("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_FUSED_TAIL")) fused_tail_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
+  if (const char *e = getenv("CFR_TAPER_FLOOR")) taper_floor_ = strtoull(e, nullptr, 10);
 
   bool layout_rb = false;
   if (const char *e = getenv("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
@@ -205,11 +206,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.ftabx = nullptr;
   view_.ftabx_width = 0;
   {
-    // auto: about one K-mer per text position (an unmatched strand then ends inside the lookup), at least 2 characters
+    // auto: several K-mers per text position (an unmatched strand then ends inside the lookup; measured: 16 beats 15 on a
+    // 1 Gbp index by 7 % of the search kernel), at least 2 characters
     // wider than the on-disk ftab, at most 16 (68 GB) and never more than a quarter of the free HBM
     uint32_t log4n = 0;
     while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
-    uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 1));
+    uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 2));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
       while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
@@ -579,10 +581,26 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
-  size_t sb = stride ? std::max(sub_batch_, (n + kMaxSub - 1) / kMaxSub) : n;     // row-space matches: one piece
-  const size_t nsub = (n + sb - 1) / sb;
+  // pieces: full sub-batches, then the last one is halved down to taper_floor_ reads so that the copy left exposed
+  // after the last kernel is small (every piece's D2H copy overlaps the kernels of the next one)
+  const size_t kTaperMax = 4;
+  size_t sb = stride ? std::max(sub_batch_, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;     // row-space matches: one piece
+  std::vector<std::pair<size_t, size_t>> pieces;
+  {
+    size_t lo = 0;
+    while (n - lo > sb) { pieces.emplace_back(lo, sb); lo += sb; }
+    size_t rem = n - lo;
+    for (size_t t = 0; stride && taper_floor_ && t + 1 < kTaperMax && rem > 2 * taper_floor_; ++t) {
+      const size_t c = rem / 2;
+      pieces.emplace_back(lo, c);
+      lo += c;
+      rem -= c;
+    }
+    pieces.emplace_back(lo, rem);
+  }
+  const size_t nsub = pieces.size();
   for (size_t k = 0; k < nsub; ++k) {
-    const size_t lo = k * sb, cnt = std::min(sb, n - lo);
+    const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
     ev_ = evs_[k];
     Pipe p;
