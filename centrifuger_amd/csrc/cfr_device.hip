@@ -196,6 +196,20 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.tax_orig = upload(h.tax.orig_taxid);
   view_.seq_to_tax = upload(h.tax.seq_to_tax);
   view_.tax_rank = upload(h.tax.rank);
+  {
+    const auto &par = h.tax.parent;
+    std::vector<uint32_t> depth(par.size(), 0xffffffffu);
+    std::vector<uint64_t> path;
+    for (uint64_t x0 = 0; x0 < par.size(); ++x0) {
+      path.clear();
+      uint64_t x = x0;
+      while (depth[x] == 0xffffffffu && par[x] != x && par[x] < par.size() && path.size() <= par.size()) { path.push_back(x); x = par[x]; }
+      uint32_t d = depth[x] == 0xffffffffu ? 0u : depth[x];
+      if (depth[x] == 0xffffffffu) depth[x] = 0;
+      for (size_t k = path.size(); k-- > 0;) depth[path[k]] = ++d;
+    }
+    view_.tax_depth = upload(depth);
+  }
   view_.node_cnt = h.tax.node_cnt;
   view_.seq_cnt = h.tax.seq_cnt;
   view_.tax_root = h.tax.root;

@@ -71,6 +71,7 @@ struct DevView {            // passed by value to kernels
   int32_t max_result;
   const uint64_t *tax_parent, *tax_orig, *seq_to_tax;
   const uint8_t *tax_rank;
+  const uint32_t *tax_depth;  // derived: steps from a node to the root (what Taxonomy::LCA's walk counts)
   uint64_t node_cnt, seq_cnt, tax_root;
   uint64_t secondary_hit_len;
   double secondary_factor;

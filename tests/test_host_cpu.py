@@ -180,3 +180,21 @@ def test_cli_rejects_out_of_scope_options_and_missing_index(golden_dir):
     if capi.device_count() == 0:
         r = subprocess.run([cli, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq")], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode != 0 and b"no CPU fallback" in r.stderr
+
+
+def test_tail_sorting_network_sorts_every_input():
+    """The 8-key comparator network the device tail uses in registers (CFR_NET8 in cfr_kernels.hip.inc), read from the
+    source and checked exhaustively on 0/1 inputs (zero-one principle)."""
+    import itertools
+    import re
+    src = open(os.path.join(ROOT, "centrifuger_amd", "csrc", "cfr_kernels.hip.inc")).read()
+    body = src[src.index("#define CFR_NET8(CE)"):]
+    body = body[:body.index("\n\n")]
+    net = [(int(a), int(b)) for a, b in re.findall(r"CE\((\d),(\d)\)", body)]
+    assert len(net) == 19
+    for bits in itertools.product([0, 1], repeat=8):
+        a = list(bits)
+        for i, j in net:
+            if a[i] > a[j]:
+                a[i], a[j] = a[j], a[i]
+        assert a == sorted(a)
