@@ -21,6 +21,8 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -66,13 +68,17 @@ void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp
 }
 
 // ---- FASTA/FASTQ (optionally gz) record reader; id = first word of the header -----------------
+// Block reads (16 MB) + memchr line splitting; sequence lines are appended straight into the batch's flat buffers
+// (no per-record strings).  Record grammar as in the reference's kseq use (ReadFiles.hpp:94-160): multi-line FASTA and
+// FASTQ, '>' or '@' headers, id up to the first blank, trailing /1 or /2 removed (ReadFiles.hpp:82-90).
 class SeqReader {
  public:
-  explicit SeqReader(const std::vector<std::string> &files) : files_(files) {}
+  explicit SeqReader(const std::vector<std::string> &files) : files_(files), buf_(1u << 24) {}
   ~SeqReader() { if (fp_) gzclose(fp_); }
 
+  // Appends the next record: id (NUL-terminated) to ids, bases to seq, quality to qual when it is wanted.
   // returns false at the end of all files
-  bool next(std::string &id, std::string &seq, std::string &qual, bool &has_qual) {
+  bool next(std::vector<char> *ids, std::vector<uint8_t> &seq, std::vector<char> *qual, bool &has_qual) {
     for (;;) {
       if (!fp_) {
         if (file_idx_ >= files_.size()) return false;
@@ -80,73 +86,104 @@ class SeqReader {
         fp_ = f == "-" ? gzdopen(fileno(stdin), "r") : gzopen(f.c_str(), "r");
         if (!fp_) { print_log("ERROR: cannot open read file %s", f.c_str()); exit(EXIT_FAILURE); }
         gzbuffer(fp_, 1 << 20);
-        have_line_ = false;
+        have_header_ = false;
+        pos_ = end_ = 0;
+        eof_ = false;
       }
-      if (read_record(id, seq, qual, has_qual)) return true;
+      if (read_record(ids, seq, qual, has_qual)) return true;
       gzclose(fp_);
       fp_ = nullptr;
     }
   }
 
  private:
-  bool getline(std::string &line) {
-    line.clear();
-    char buf[1 << 16];
+  // next line without its line terminator; the view is valid until the next call.  false: nothing left.
+  bool next_line(const char *&p, size_t &n) {
     for (;;) {
-      if (!gzgets(fp_, buf, sizeof(buf))) return !line.empty();
-      size_t n = strlen(buf);
-      bool eol = n && buf[n - 1] == '\n';
-      while (n && (buf[n - 1] == '\n' || buf[n - 1] == '\r')) --n;
-      line.append(buf, n);
-      if (eol) return true;
-    }
-  }
-  bool read_record(std::string &id, std::string &seq, std::string &qual, bool &has_qual) {
-    if (!have_line_) {
-      do { if (!getline(line_)) return false; } while (line_.empty() || (line_[0] != '>' && line_[0] != '@'));
-    }
-    have_line_ = false;
-    const bool fastq = line_[0] == '@';
-    size_t e = 1;
-    while (e < line_.size() && line_[e] != ' ' && line_[e] != '\t') ++e;
-    id.assign(line_, 1, e - 1);
-    // ReadFiles::RemoveReadIdSuffix (ReadFiles.hpp:82-90)
-    if (id.size() >= 2 && id[id.size() - 2] == '/' && (id.back() == '1' || id.back() == '2')) id.resize(id.size() - 2);
-    seq.clear();
-    qual.clear();
-    has_qual = false;
-    while (getline(line_)) {
-      if (line_.empty()) continue;
-      if (line_[0] == '>' || (!fastq && line_[0] == '@')) { have_line_ = true; return true; }
-      if (fastq && line_[0] == '+') {
-        has_qual = true;
-        while (qual.size() < seq.size() && getline(line_)) qual += line_;
+      char *base = buf_.data();
+      if (char *nl = (char *)memchr(base + pos_, '\n', end_ - pos_)) {
+        p = base + pos_;
+        n = (size_t)(nl - p);
+        pos_ = (size_t)(nl - base) + 1;
+        while (n && p[n - 1] == '\r') --n;
         return true;
       }
-      if (fastq && line_[0] == '@' && !seq.empty()) { have_line_ = true; return true; }
-      seq += line_;
+      if (eof_) {
+        if (pos_ == end_) return false;
+        p = base + pos_;
+        n = end_ - pos_;
+        pos_ = end_;
+        while (n && p[n - 1] == '\r') --n;
+        return n > 0;
+      }
+      if (pos_) { memmove(base, base + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+      if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+      const int got = gzread(fp_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
+      if (got <= 0) eof_ = true; else end_ += (size_t)got;
+    }
+  }
+  bool read_record(std::vector<char> *ids, std::vector<uint8_t> &seq, std::vector<char> *qual, bool &has_qual) {
+    const char *p;
+    size_t n;
+    if (have_header_) { p = header_.data(); n = header_.size(); }
+    else {
+      do { if (!next_line(p, n)) return false; } while (n == 0 || (p[0] != '>' && p[0] != '@'));
+    }
+    have_header_ = false;
+    const bool fastq = p[0] == '@';
+    size_t e = 1;
+    while (e < n && p[e] != ' ' && p[e] != '\t') ++e;
+    size_t idn = e - 1;
+    if (idn >= 2 && p[e - 2] == '/' && (p[e - 1] == '1' || p[e - 1] == '2')) idn -= 2;
+    if (ids) { ids->insert(ids->end(), p + 1, p + 1 + idn); ids->push_back('\0'); }
+    has_qual = false;
+    size_t seq_n = 0;
+    while (next_line(p, n)) {
+      if (n == 0) continue;
+      if (p[0] == '>' || (!fastq && p[0] == '@')) { header_.assign(p, n); have_header_ = true; return true; }
+      if (fastq && p[0] == '+') {
+        has_qual = true;
+        size_t qn = 0;
+        while (qn < seq_n && next_line(p, n)) { if (qual) qual->insert(qual->end(), p, p + n); qn += n; }
+        return true;
+      }
+      if (fastq && p[0] == '@' && seq_n) { header_.assign(p, n); have_header_ = true; return true; }
+      seq.insert(seq.end(), (const uint8_t *)p, (const uint8_t *)p + n);
+      seq_n += n;
     }
     return true;
   }
   std::vector<std::string> files_;
   size_t file_idx_ = 0;
   gzFile fp_ = nullptr;
-  std::string line_;
-  bool have_line_ = false;
+  std::vector<char> buf_;
+  size_t pos_ = 0, end_ = 0;
+  bool eof_ = false;
+  std::string header_;
+  bool have_header_ = false;
 };
 
 struct Batch {
   size_t seq_no = 0;
   size_t n = 0;
   bool paired = false;
-  std::vector<std::string> ids, qual1, qual2;
-  std::vector<uint8_t> has_qual;
+  std::vector<char> ids;               // NUL-terminated ids back to back
+  std::vector<size_t> id_off;
+  std::vector<char> qual1, qual2;      // only filled when reads are dumped (--un / --cl)
+  std::vector<size_t> q1_off, q2_off;
+  std::vector<uint8_t> has_qual, has_qual2;
   std::vector<uint8_t> bases1, bases2;
   std::vector<uint64_t> offs1, offs2;
   std::vector<cfr_result> results;
   std::vector<cfr_match> matches;
   std::string tsv;
   bool done = false;
+  const char *id(size_t i) const { return ids.data() + id_off[i]; }
+  void reset() {   // keeps every buffer's capacity: batches are recycled, so steady state allocates (and page-faults) nothing
+    n = 0; done = false;
+    ids.clear(); id_off.clear(); qual1.clear(); qual2.clear(); q1_off.clear(); q2_off.clear(); has_qual.clear(); has_qual2.clear();
+    bases1.clear(); bases2.clear(); offs1.clear(); offs2.clear(); tsv.clear();
+  }
 };
 
 struct Options {
@@ -158,7 +195,7 @@ struct Options {
   std::string un_prefix, cl_prefix;
   std::vector<int> gpus{0};
   bool all_gpus = false;
-  size_t gpu_batch = 1u << 20;
+  size_t gpu_batch = 1u << 18;
 };
 
 // gz read dumps (ResultWriter::SetOutputReads, ResultWriter.hpp:126-176)
@@ -172,13 +209,24 @@ struct ReadDump {
       fp[0] = gzopen((prefix + ".fq.gz").c_str(), "w1");
     }
   }
-  void put(int k, const std::string &id, const uint8_t *s, size_t n, const std::string *q) {
+  void put(int k, const char *id, const uint8_t *s, size_t n, const char *q, size_t qn) {
     if (!fp[k]) return;
-    if (!q) gzprintf(fp[k], ">%s\n%.*s\n", id.c_str(), (int)n, (const char *)s);
-    else gzprintf(fp[k], "@%s\n%.*s\n+\n%s\n", id.c_str(), (int)n, (const char *)s, q->c_str());
+    if (!q) gzprintf(fp[k], ">%s\n%.*s\n", id, (int)n, (const char *)s);
+    else gzprintf(fp[k], "@%s\n%.*s\n+\n%.*s\n", id, (int)n, (const char *)s, (int)qn, q);
   }
   void close() { for (auto &f : fp) if (f) { gzclose(f); f = nullptr; } }
 };
+
+// CFR_CLI_TIMING=1: per-stage busy seconds on stderr at exit (stage threads overlap, so they do not add up to the wall clock)
+struct StageClock {
+  std::atomic<long long> ns[8];
+  StageClock() { for (auto &x : ns) x = 0; }
+  void add(int k, std::chrono::steady_clock::time_point t0) {
+    ns[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+enum { T_OPEN = 0, T_DEVICE, T_PARSE, T_DUST, T_CLASSIFY, T_FORMAT, T_WRITE, T_WALL };
+inline std::chrono::steady_clock::time_point tick() { return std::chrono::steady_clock::now(); }
 
 [[noreturn]] void die_status(const char *what, cfr_status st) {
   print_log("ERROR: %s failed (status %d): %s", what, st, cfr_last_error());
@@ -252,28 +300,42 @@ int main(int argc, char *argv[]) {
   if (opt.m1.size() != opt.m2.size()) { print_log("ERROR: -1 and -2 must be given the same number of times."); return EXIT_FAILURE; }
   if (opt.u.empty() && !paired) { print_log("Need to use -u/-1/-2/-i to specify input reads."); return EXIT_FAILURE; }
 
-  cfr_index *idx = nullptr;
-  cfr_status st = cfr_index_open(opt.idx.c_str(), &opt.params, &idx);
-  if (st != CFR_OK) die_status("loading the index", st);
-  cfr_index_info info;
-  cfr_index_get_info(idx, &info);
-  print_log("Finishes loading index.");
-  if (opt.params.min_hit_len <= 0) print_log("Inferred --min-hitlen: %d", info.min_hit_len);
-  if (opt.all_gpus) {
-    int cnt = 0;
-    cfr_device_count(&cnt);
-    opt.gpus.clear();
-    for (int g = 0; g < cnt; ++g) opt.gpus.push_back(g);
+  if (const char *e = getenv("CFR_CLI_PARSE_ONLY")) if (atoi(e)) {
+    // parser self-test hook (tests/test_host_cpu.py): records as "id<TAB>bases[<TAB>mate bases]<TAB>q|-" lines; no index, no device
+    std::unique_ptr<SeqReader> r1, r2;
+    const bool interleaved = !opt.inter.empty();
+    if (interleaved) r1.reset(new SeqReader(opt.inter));
+    else if (paired) { r1.reset(new SeqReader(opt.m1)); r2.reset(new SeqReader(opt.m2)); }
+    else r1.reset(new SeqReader(opt.u));
+    std::vector<char> ids, q;
+    std::vector<uint8_t> s1, s2;
+    bool hq = false, hq2 = false;
+    if (atoi(e) == 2) {       // count only (parser throughput)
+      size_t nrec = 0, nbase = 0;
+      const auto tp = tick();
+      for (;;) {
+        if (s1.size() > (1u << 26)) { ids.clear(); s1.clear(); s2.clear(); }
+        if (!r1->next(&ids, s1, nullptr, hq)) break;
+        if (paired && !(interleaved ? r1->next(nullptr, s2, nullptr, hq2) : r2->next(nullptr, s2, nullptr, hq2))) break;
+        ++nrec;
+      }
+      nbase = s1.size();
+      const double sec = std::chrono::duration<double>(tick() - tp).count();
+      printf("%zu records in %.3f s = %.2f M records/s (%zu)\n", nrec, sec, (double)nrec / sec * 1e-6, nbase);
+      return 0;
+    }
+    for (;;) {
+      ids.clear(); s1.clear(); s2.clear(); q.clear();
+      if (!r1->next(&ids, s1, &q, hq)) break;
+      if (paired && !(interleaved ? r1->next(nullptr, s2, nullptr, hq2) : r2->next(nullptr, s2, nullptr, hq2))) { fputs("MATE_MISSING\n", stdout); break; }
+      printf("%s\t%.*s", ids.data(), (int)s1.size(), (const char *)s1.data());
+      if (paired) printf("\t%.*s", (int)s2.size(), (const char *)s2.data());
+      printf("\t%s%.*s\n", hq ? "q:" : "-", (int)q.size(), q.data());
+    }
+    return 0;
   }
-  std::vector<cfr_dev_index *> devs;
-  for (int g : opt.gpus) {
-    cfr_dev_index *d = nullptr;
-    st = cfr_device_index_create(idx, g, &d);
-    if (st != CFR_OK) die_status("creating the device index (this build has no CPU fallback)", st);
-    devs.push_back(d);
-  }
-  if (devs.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }
-
+  StageClock clk;
+  const auto t_wall = tick();
   ReadDump un, cl;
   if (!opt.un_prefix.empty()) un.open(opt.un_prefix, paired);
   if (!opt.cl_prefix.empty()) cl.open(opt.cl_prefix, paired);
@@ -284,8 +346,9 @@ int main(int argc, char *argv[]) {
   std::condition_variable cv;
   std::deque<std::shared_ptr<Batch>> pending;      // parsed, waiting for a device
   std::deque<std::shared_ptr<Batch>> in_order;     // every batch in input order, for the writer
+  std::deque<std::shared_ptr<Batch>> recycled;     // written out; their buffers serve the next batches
   bool reader_done = false;
-  const size_t max_inflight = devs.size() * 2 + 1;
+  const size_t max_inflight = 16;                  // parsed batches waiting (the reader runs ahead of the index load)
 
   std::thread reader([&]() {
     std::unique_ptr<SeqReader> r1, r2;
@@ -295,33 +358,43 @@ int main(int argc, char *argv[]) {
     else r1.reset(new SeqReader(opt.u));
     size_t seq_no = 0;
     bool more = true;
+    const bool keep_qual = !opt.un_prefix.empty() || !opt.cl_prefix.empty();
     while (more) {
-      auto b = std::make_shared<Batch>();
+      const auto tp = tick();
+      std::shared_ptr<Batch> b;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!recycled.empty()) { b = recycled.front(); recycled.pop_front(); }
+      }
+      if (!b) b = std::make_shared<Batch>();
+      b->reset();
       b->seq_no = seq_no++;
       b->paired = paired;
       b->offs1.push_back(0);
       if (paired) b->offs2.push_back(0);
-      std::string id, s, q, id2, s2, q2;
       bool hq = false, hq2 = false;
+      b->q1_off.push_back(0);
+      b->q2_off.push_back(0);
       while (b->n < opt.gpu_batch) {
-        if (!r1->next(id, s, q, hq)) { more = false; break; }
+        const size_t id_at = b->ids.size();
+        if (!r1->next(&b->ids, b->bases1, keep_qual ? &b->qual1 : nullptr, hq)) { more = false; break; }
         if (paired) {
-          bool ok = interleaved ? r1->next(id2, s2, q2, hq2) : r2->next(id2, s2, q2, hq2);
+          bool ok = interleaved ? r1->next(nullptr, b->bases2, keep_qual ? &b->qual2 : nullptr, hq2)
+                                : r2->next(nullptr, b->bases2, keep_qual ? &b->qual2 : nullptr, hq2);
           if (!ok) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
-          b->bases2.insert(b->bases2.end(), s2.begin(), s2.end());
           b->offs2.push_back(b->bases2.size());
-          b->qual2.push_back(hq2 ? q2 : std::string());
+          if (keep_qual) { b->q2_off.push_back(b->qual2.size()); b->has_qual2.push_back(hq2 ? 1 : 0); }
         }
-        b->ids.push_back(id);
-        b->bases1.insert(b->bases1.end(), s.begin(), s.end());
+        b->id_off.push_back(id_at);
         b->offs1.push_back(b->bases1.size());
-        b->qual1.push_back(hq ? q : std::string());
-        b->has_qual.push_back(hq ? 1 : 0);
+        if (keep_qual) { b->q1_off.push_back(b->qual1.size()); b->has_qual.push_back(hq ? 1 : 0); }
         ++b->n;
       }
       if (!more && paired && !interleaved) {
-        if (r2->next(id2, s2, q2, hq2)) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+        std::vector<uint8_t> extra;
+        if (r2->next(nullptr, extra, nullptr, hq2)) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
       }
+      clk.add(T_PARSE, tp);
       if (b->n == 0) break;
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&]() { return in_order.size() < max_inflight; });
@@ -334,6 +407,35 @@ int main(int argc, char *argv[]) {
     cv.notify_all();
   });
 
+  // ---- index load and device image, while the reader thread already parses the first batches
+  auto t0 = tick();
+  cfr_index *idx = nullptr;
+  cfr_status st = cfr_index_open(opt.idx.c_str(), &opt.params, &idx);
+  if (st != CFR_OK) die_status("loading the index", st);
+  clk.add(T_OPEN, t0);
+  cfr_index_info info;
+  cfr_index_get_info(idx, &info);
+  print_log("Finishes loading index.");
+  if (opt.params.min_hit_len <= 0) print_log("Inferred --min-hitlen: %d", info.min_hit_len);
+  if (opt.all_gpus) {
+    int cnt = 0;
+    cfr_device_count(&cnt);
+    opt.gpus.clear();
+    for (int g = 0; g < cnt; ++g) opt.gpus.push_back(g);
+  }
+  std::vector<cfr_dev_index *> devs;
+  t0 = tick();
+  setenv("CFR_PROFILE", "fast-load", 0);     // this program is bound by parsing; prefer a short load (export CFR_PROFILE=throughput to build every table)
+  for (int g : opt.gpus) {
+    cfr_dev_index *d = nullptr;
+    st = cfr_device_index_create(idx, g, &d);
+    if (st != CFR_OK) die_status("creating the device index (this build has no CPU fallback)", st);
+    devs.push_back(d);
+  }
+  if (devs.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }
+  clk.add(T_DEVICE, t0);
+
+
   auto worker = [&](cfr_dev_index *dev) {
     for (;;) {
       std::shared_ptr<Batch> b;
@@ -344,10 +446,13 @@ int main(int argc, char *argv[]) {
         b = pending.front();
         pending.pop_front();
       }
+      auto ts = tick();
       if (opt.dust) {   // CentrifugerClass.cpp:276-316
         cfr_dust_mask_batch(b->bases1.data(), b->offs1.data(), b->n, opt.threads);
         if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data(), b->n, opt.threads);
       }
+      clk.add(T_DUST, ts);
+      ts = tick();
       b->results.resize(b->n);
       size_t cap = b->n * (size_t)(opt.params.max_result > 0 ? opt.params.max_result : 4) + 16, used = 0;
       for (;;) {
@@ -358,6 +463,8 @@ int main(int argc, char *argv[]) {
         if (s != CFR_OK) die_status("cfr_classify_batch", s);
         break;
       }
+      clk.add(T_CLASSIFY, ts);
+      ts = tick();
       // TSV rows (ResultWriter::Output), formatted in parallel slices then concatenated in order
       const int nt = (int)std::min<size_t>((size_t)opt.threads, std::max<size_t>(1, b->n / 4096));
       std::vector<std::string> parts((size_t)nt);
@@ -366,11 +473,11 @@ int main(int argc, char *argv[]) {
         std::string &out = parts[(size_t)t];
         char buf[8192];
         for (size_t i = lo; i < hi; ++i) {
-          size_t w = cfr_format_tsv(idx, b->ids[i].c_str(), &b->results[i], b->matches.data(), buf, sizeof(buf));
+          size_t w = cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), buf, sizeof(buf));
           if (w < sizeof(buf)) out.append(buf, w);
           else {
             std::string big(w + 1, '\0');
-            cfr_format_tsv(idx, b->ids[i].c_str(), &b->results[i], b->matches.data(), &big[0], big.size());
+            cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), &big[0], big.size());
             out.append(big.data(), w);
           }
         }
@@ -382,6 +489,7 @@ int main(int argc, char *argv[]) {
         for (auto &x : th) x.join();
       }
       for (auto &p : parts) b->tsv += p;
+      clk.add(T_FORMAT, ts);
       std::lock_guard<std::mutex> lk(mu);
       b->done = true;
       cv.notify_all();
@@ -401,6 +509,7 @@ int main(int argc, char *argv[]) {
       in_order.pop_front();
       cv.notify_all();
     }
+    const auto tw = tick();
     fwrite(b->tsv.data(), 1, b->tsv.size(), stdout);
     for (size_t i = 0; i < b->n; ++i) {
       const bool hit = b->results[i].n_match > 0;
@@ -408,10 +517,15 @@ int main(int argc, char *argv[]) {
       classified += hit ? 1 : 0;
       ReadDump *dump = hit ? (cl.fp[0] ? &cl : nullptr) : (un.fp[0] ? &un : nullptr);
       if (!dump) continue;
-      dump->put(0, b->ids[i], b->bases1.data() + b->offs1[i], b->offs1[i + 1] - b->offs1[i], b->has_qual[i] ? &b->qual1[i] : nullptr);
+      dump->put(0, b->id(i), b->bases1.data() + b->offs1[i], b->offs1[i + 1] - b->offs1[i],
+                b->has_qual[i] ? b->qual1.data() + b->q1_off[i] : nullptr, b->q1_off[i + 1] - b->q1_off[i]);
       if (b->paired)
-        dump->put(1, b->ids[i], b->bases2.data() + b->offs2[i], b->offs2[i + 1] - b->offs2[i], b->qual2[i].empty() ? nullptr : &b->qual2[i]);
+        dump->put(1, b->id(i), b->bases2.data() + b->offs2[i], b->offs2[i + 1] - b->offs2[i],
+                  b->has_qual2[i] ? b->qual2.data() + b->q2_off[i] : nullptr, b->q2_off[i + 1] - b->q2_off[i]);
     }
+    clk.add(T_WRITE, tw);
+    std::lock_guard<std::mutex> lk(mu);
+    recycled.push_back(b);
   }
   reader.join();
   for (auto &w : workers) w.join();
@@ -423,6 +537,11 @@ int main(int argc, char *argv[]) {
             total ? (double)classified / (double)total * 100.0 : 0.0);
   for (auto *d : devs) cfr_device_index_destroy(d);
   cfr_index_destroy(idx);
+  clk.add(T_WALL, t_wall);
+  if (const char *e = getenv("CFR_CLI_TIMING")) if (atoi(e)) {
+    static const char *names[] = {"index_open", "device_index", "parse", "dust", "classify", "format", "write", "wall"};
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "[timing] %-12s %8.3f s\n", names[k], (double)clk.ns[k].load() * 1e-9);
+  }
   print_log("Centrifuger finishes.");
   return 0;
 }

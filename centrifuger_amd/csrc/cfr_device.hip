@@ -2,6 +2,7 @@
 #include "cfr_device.hpp"
 
 #include <hipcub/hipcub.hpp>
+#include <chrono>
 
 #include <algorithm>
 #include <cstdlib>
@@ -76,12 +77,28 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
   if (const char *e = getenv("CFR_TAPER_FLOOR")) taper_floor_ = strtoull(e, nullptr, 10);
 
+  // CFR_LOAD_TIMING=1: seconds per load stage on stderr
+  const bool load_timing = getenv("CFR_LOAD_TIMING") && atoi(getenv("CFR_LOAD_TIMING"));
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!load_timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[load] %-28s %7.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  lap("context, streams, events");
+  // CFR_PROFILE=fast-load: skip the large derived tables (a command-line run is bound by FASTQ parsing, not by the device;
+  // what it feels is the load time).  Default: throughput (all tables).  The specific switches below override either.
+  const bool fast_load = getenv("CFR_PROFILE") && std::string(getenv("CFR_PROFILE")) == "fast-load";
   bool layout_rb = false;
   if (const char *e = getenv("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
   memset(&view_.rb, 0, sizeof(view_.rb));
   uint64_t *d_occ = nullptr;
-  if (layout_rb) {
-    // ---- run-block image: the 7 bitvectors as rank lines (cfr_device.hpp); no flat occ array at all
+  {
+    // ---- run-block image: the 7 bitvectors as rank lines (cfr_device.hpp).  CFR_LAYOUT=rb searches on it directly;
+    // otherwise it is only the source the flat occ image is expanded from (on the device) and is freed afterwards.
+    std::vector<void *> rb_allocs;
     auto lines_of = [&](const RawBitvector &bv) -> RankLines {
       const uint64_t nl = bv.n / 448 + 2;
       std::vector<uint64_t> L(nl * 8, 0);
@@ -102,7 +119,11 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
           ones += (uint64_t)__builtin_popcountll(w);
         }
       }
-      return RankLines{upload(L), bv.n};
+      uint64_t *d = nullptr;
+      HIP_CHECK(hipMalloc((void **)&d, L.size() * 8));
+      rb_allocs.push_back(d);
+      HIP_CHECK(hipMemcpy(d, L.data(), L.size() * 8, hipMemcpyHostToDevice));
+      return RankLines{d, bv.n};
     };
     view_.rb.use = lines_of(h.use_run_block);
     for (int k = 0; k < 3; ++k) {
@@ -115,52 +136,52 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     view_.rb.b = h.b;
     view_.rb.block_cnt = h.block_cnt;
     view_.rb.filter_rate = (uint32_t)h.selected_filter_rate;
-    if (!h.selected_rows.empty()) {
-      std::vector<uint64_t> filt(((h.n + view_.rb.filter_rate - 1) / view_.rb.filter_rate + 63) / 64 + 1, 0);
-      for (uint64_t r : h.selected_rows) { const uint64_t fb = r / view_.rb.filter_rate; filt[fb >> 6] |= 1ull << (fb & 63); }
-      view_.rb.sel_filter = upload(filt);
+    lap("rank lines (host) + upload");
+    if (layout_rb) {
+      for (void *q : rb_allocs) owned_.push_back(q);
+      if (!h.selected_rows.empty()) {
+        std::vector<uint64_t> filt(((h.n + view_.rb.filter_rate - 1) / view_.rb.filter_rate + 63) / 64 + 1, 0);
+        for (uint64_t r : h.selected_rows) { const uint64_t fb = r / view_.rb.filter_rate; filt[fb >> 6] |= 1ull << (fb & 63); }
+        view_.rb.sel_filter = upload(filt);
+      }
+      view_.rb.enabled = 1;
+      search_v1_ = true;                 // the state-machine kernel reads the flat occ records directly
+    } else {
+      // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp), expanded from the image above
+      const uint64_t nrec = (h.n >> 7) + 2, halves = nrec * 2;
+      d_occ = dev_alloc<uint64_t>(nrec * 8);
+      uint64_t *d_cnt = nullptr, *d_pre = nullptr;
+      HIP_CHECK(hipMalloc((void **)&d_cnt, 3 * (halves + 1) * 8));
+      HIP_CHECK(hipMalloc((void **)&d_pre, 3 * (halves + 1) * 8));
+      HIP_CHECK(hipMemsetAsync(d_cnt, 0, 3 * (halves + 1) * 8, stream_));
+      const unsigned g = (unsigned)std::min<uint64_t>((halves + 255) / 256, 1u << 20);
+      k_occ_expand<<<g, 256, 0, stream_>>>(view_.rb, h.n, halves, d_occ, d_cnt);
+      HIP_CHECK(hipGetLastError());
+      size_t tmp_bytes = 0;
+      HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_pre, (int)(halves + 1), stream_));
+      void *d_tmp = nullptr;
+      HIP_CHECK(hipMalloc(&d_tmp, tmp_bytes));
+      for (int c = 0; c < 3; ++c)
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt + c * (halves + 1), d_pre + c * (halves + 1), (int)(halves + 1), stream_));
+      k_occ_fill_mid<<<g, 256, 0, stream_>>>(halves, d_pre, d_occ);
+      HIP_CHECK(hipGetLastError());
+      if (!h.selected_rows.empty()) {
+        uint64_t *d_sel = nullptr;
+        HIP_CHECK(hipMalloc((void **)&d_sel, h.selected_rows.size() * 8));
+        HIP_CHECK(hipMemcpyAsync(d_sel, h.selected_rows.data(), h.selected_rows.size() * 8, hipMemcpyHostToDevice, stream_));
+        k_occ_flag_selected<<<(unsigned)((h.selected_rows.size() + 255) / 256), 256, 0, stream_>>>(d_sel, h.selected_rows.size(), d_occ, kSelFlag);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        HIP_CHECK(hipFree(d_sel));
+      }
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      HIP_CHECK(hipFree(d_tmp));
+      HIP_CHECK(hipFree(d_cnt));
+      HIP_CHECK(hipFree(d_pre));
+      for (void *q : rb_allocs) HIP_CHECK(hipFree(q));
+      memset(&view_.rb, 0, sizeof(view_.rb));
+      lap("occ expansion (device)");
     }
-    view_.rb.enabled = 1;
-    search_v1_ = true;                 // the state-machine kernel reads the flat occ records directly
-  } else {
-  // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp)
-  const uint64_t nrec = (h.n >> 7) + 2;
-  std::vector<uint64_t> occ(nrec * 8, 0);
-  uint64_t run[4] = {0, 0, 0, 0};   // #c in B[0 .. 64*k)
-  const uint64_t halves = nrec * 2;
-  for (uint64_t k = 0; k < halves; ++k) {
-    // symbols [64k, 64k+64): two packed words of 32 symbols (padding beyond n is symbol 0, counted consistently)
-    uint64_t lo = 0, hi = 0;
-    for (int wq = 0; wq < 2; ++wq) {
-      const uint64_t wi = 2 * k + wq;
-      uint64_t w = wi < h.bwt2.size() ? h.bwt2[wi] : 0;
-      // de-interleave 2-bit symbols into bit planes
-      uint64_t l = w & 0x5555555555555555ull, u = (w >> 1) & 0x5555555555555555ull;
-      auto squeeze = [](uint64_t x) {
-        x = (x | (x >> 1)) & 0x3333333333333333ull;
-        x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
-        x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
-        x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
-        x = (x | (x >> 16)) & 0x00000000ffffffffull;
-        return x;
-      };
-      lo |= squeeze(l) << (32 * wq);
-      hi |= squeeze(u) << (32 * wq);
-    }
-    uint64_t *rec = &occ[(k >> 1) * 8];
-    if (k & 1) {
-      // entering the second half: run[] == #c before the midpoint
-      for (int c = 0; c < 4; ++c) rec[c] = run[c];
-    }
-    rec[4 + 2 * (k & 1)] = lo;
-    rec[5 + 2 * (k & 1)] = hi;
-    const uint64_t c3 = (uint64_t)__builtin_popcountll(lo & hi), c2 = (uint64_t)__builtin_popcountll(~lo & hi),
-                   c1 = (uint64_t)__builtin_popcountll(lo & ~hi);
-    run[3] += c3; run[2] += c2; run[1] += c1; run[0] += 64 - c3 - c2 - c1;
-  }
-  for (uint64_t r : h.selected_rows) occ[(r >> 7) * 8] |= kSelFlag;
-  d_occ = dev_alloc<uint64_t>(occ.size());
-  HIP_CHECK(hipMemcpy(d_occ, occ.data(), occ.size() * 8, hipMemcpyHostToDevice));
   }
 
   uint64_t *d_ftab = dev_alloc<uint64_t>(h.ftab.size());
@@ -229,6 +250,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
       while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
+    if (fast_load) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
     if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
@@ -241,11 +263,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       view_.ftabx_width = K;
     } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; }   // optional table: run without it
   }
+  lap("side tables + ftabx");
   // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
   view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
-    bool want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb;
-    if (const char *e = getenv("CFR_TEXT_MODE")) want = want && atoi(e) != 0;
+    bool want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb && !fast_load;
+    if (const char *e = getenv("CFR_TEXT_MODE")) want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb && atoi(e) != 0;
     if (want) try {
       uint2 *la = nullptr, *lb = nullptr;
       HIP_CHECK(hipMalloc((void **)&la, h.n * sizeof(uint2)));
@@ -275,11 +298,12 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       if (const char *e = getenv("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
     } catch (const HipError &) { (void)hipGetLastError(); view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; }   // optional tables
   }
+  lap("SA / ISA / text (list ranking)");
   // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
   view_.loc_memo = nullptr;
   view_.memo_shift = 0;
   {
-    double budget_gb = 16.0;
+    double budget_gb = fast_load ? 0.0 : 16.0;
     if (const char *e = getenv("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;
     for (uint64_t x : h.selected_vals) max_val = std::max(max_val, x);
@@ -296,6 +320,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
       view_.memo_shift = shift;
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
   }
+  lap("locate memo");
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }

@@ -126,45 +126,23 @@ void parse_wavelet(Cursor &c, RawWavelet &w) {
 
 inline unsigned bit_at(const RawBitvector &bv, uint64_t i) { return (unsigned)((bv.bits[i >> 6] >> (i & 63)) & 1); }
 
-// Sequential reader of a wavelet-coded sequence: no rank needed when symbols are taken in order.
-class WaveletStream {
- public:
-  explicit WaveletStream(const RawWavelet &w) : w_(w) {}
-  unsigned next() {
-    unsigned hi = bit_at(w_.node[0], pos_++);
-    const RawBitvector &child = w_.node[w_.children[0][hi]];
-    unsigned lo = bit_at(child, child_pos_[hi]++);
-    return (hi << 1) | lo;
+// The three run-block components must describe exactly n symbols (Sequence_RunBlock.hpp:15-20): one run-block symbol
+// per set bit of useRunBlock, and the plain sequence holds what the other blocks cover.  (The BWT itself is never
+// decoded on the host: the device expands its flat image from these components, cfr_device.hip.)
+void check_run_block_lengths(const HostIndex &h) {
+  uint64_t runs = 0;
+  for (uint64_t w = 0; w * 64 < h.block_cnt; ++w) {
+    uint64_t x = h.use_run_block.bits[w];
+    if ((w + 1) * 64 > h.block_cnt) x &= (1ull << (h.block_cnt - w * 64)) - 1;
+    runs += (uint64_t)__builtin_popcountll(x);
   }
-  uint64_t consumed() const { return pos_; }
-
- private:
-  const RawWavelet &w_;
-  uint64_t pos_ = 0;
-  uint64_t child_pos_[2] = {0, 0};
-};
-
-void unpack_bwt(HostIndex &h) {
-  h.bwt2.assign(ceil_div(h.n, 32) + 1, 0);
-  WaveletStream plain(h.wavelet_seq), runs(h.run_block_seq);
-  uint64_t pos = 0;
-  auto put = [&](unsigned sym) {
-    h.bwt2[pos >> 5] |= (uint64_t)sym << ((pos & 31) * 2);
-    ++pos;
-  };
-  for (uint64_t bi = 0; bi < h.block_cnt; ++bi) {
-    uint64_t len = h.b;
-    if (pos + len > h.n) len = h.n - pos;
-    if (bit_at(h.use_run_block, bi)) {
-      if (h.run_block_seq.node_cnt == 0) throw FormatError{"run block without a run-block sequence"};
-      unsigned sym = runs.next();
-      for (uint64_t k = 0; k < len; ++k) put(sym);
-    } else {
-      for (uint64_t k = 0; k < len; ++k) put(plain.next());
-    }
-  }
-  if (pos != h.n) throw FormatError{"decoded BWT length mismatch"};
-  if (plain.consumed() != h.wavelet_seq.n || (h.run_block_seq.node_cnt && runs.consumed() != h.run_block_seq.n))
+  if (runs && h.run_block_seq.node_cnt == 0) throw FormatError{"run block without a run-block sequence"};
+  const uint64_t last_len = h.n - (h.block_cnt - 1) * h.b;
+  const bool last_is_run = h.block_cnt && bit_at(h.use_run_block, h.block_cnt - 1);
+  const uint64_t covered_by_runs = runs * h.b - (last_is_run ? h.b - last_len : 0);
+  if (covered_by_runs > h.n) throw FormatError{"decoded BWT length mismatch"};
+  const uint64_t plain = h.n - covered_by_runs;
+  if ((h.wavelet_seq.node_cnt ? h.wavelet_seq.n : 0) != plain || (h.run_block_seq.node_cnt && h.run_block_seq.n != runs))
     throw FormatError{"run-block component lengths do not add up"};
 }
 
@@ -228,7 +206,7 @@ void parse_fm(const std::string &path, HostIndex &h) {
   h.has_end_marker = false;
   if (!c.eof()) h.has_end_marker = c.get<uint8_t>() != 0;   // absent in old indexes (FMIndex.hpp:178-181)
   if (h.has_end_marker) throw FormatError{"end-marker (protein) indexes are out of scope"};
-  unpack_bwt(h);
+  check_run_block_lengths(h);
 }
 
 std::string get_string(Cursor &c) {

@@ -61,8 +61,6 @@ struct HostIndex {
   int32_t selected_filter_rate = 1024;
   std::vector<uint64_t> selected_rows, selected_vals;   // ascending rows
   bool has_end_marker = false;
-  // conceptual BWT, 2 bits per symbol, 32 symbols per word, symbol i at bits [2*(i%32), +2)
-  std::vector<uint64_t> bwt2;
   // taxonomy + parameters
   Taxonomy tax;
   cfr_params params;
@@ -75,9 +73,5 @@ struct IoError { std::string msg; };
 
 HostIndex *load_index(const std::string &prefix, const cfr_params *params);
 
-// reference 2-bit symbol at BWT position i
-inline unsigned bwt_symbol(const HostIndex &h, uint64_t i) {
-  return (unsigned)((h.bwt2[i >> 5] >> ((i & 31) * 2)) & 3);
-}
 
 }  // namespace cfr

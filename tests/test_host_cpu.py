@@ -198,3 +198,91 @@ def test_tail_sorting_network_sorts_every_input():
             if a[i] > a[j]:
                 a[i], a[j] = a[j], a[i]
         assert a == sorted(a)
+
+
+def _py_parse(data: bytes):
+    """Plain restatement of the record grammar the command line accepts (multi-line FASTA/FASTQ, CRLF, blank lines)."""
+    lines = [ln.rstrip(b"\r") for ln in data.split(b"\n")]
+    if lines and lines[-1] == b"":
+        lines.pop()
+    recs, i = [], 0
+    while i < len(lines):
+        ln = lines[i]
+        if not ln or ln[:1] not in (b">", b"@"):
+            i += 1
+            continue
+        fastq = ln[:1] == b"@"
+        rid = ln[1:].split(b" ")[0].split(b"\t")[0]
+        if len(rid) >= 2 and rid[-2:] in (b"/1", b"/2"):
+            rid = rid[:-2]
+        i += 1
+        seq, qual, hq = b"", b"", False
+        while i < len(lines):
+            ln = lines[i]
+            if not ln:
+                i += 1
+                continue
+            if ln[:1] == b">" or (not fastq and ln[:1] == b"@"):
+                break
+            if fastq and ln[:1] == b"+":
+                hq = True
+                i += 1
+                while len(qual) < len(seq) and i < len(lines):
+                    qual += lines[i]
+                    i += 1
+                break
+            if fastq and ln[:1] == b"@" and seq:
+                break
+            seq += ln
+            i += 1
+        recs.append((rid, seq, qual, hq))
+    return recs
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_cli_read_parser(tmp_path, gz):
+    """The block parser of the command line (CFR_CLI_PARSE_ONLY hook: no index, no device) on awkward inputs."""
+    import gzip
+    import subprocess
+    cli = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    rng = np.random.default_rng(5)
+
+    def dna(n):
+        return bytes(rng.choice(list(b"ACGTN"), size=n, p=[.24, .24, .24, .24, .04]).astype(np.uint8))
+    cases = {
+        "fastq4": b"".join(b"@r%d/1 desc x\n%s\n+\n%s\n" % (i, dna(50 + i), b"I" * (50 + i)) for i in range(200)),
+        "fastq_at_quality": b"@a\nACGT\n+\n@@@@\n@b extra\nGGCC\n+b\n@III\n",
+        "fasta_multiline_crlf": b">s1 first\r\nACGT\r\nGGTT\r\n\r\n>s2\r\nTTTT\r\n",
+        "fasta_no_trailing_newline": b">x\nACGTACGT\n>y/2\nGGG",
+        "fastq_multiline": b"@m1\nACGT\nACGT\n+\nIIII\nIIII\n@m2\nAC\n+\nII\n",
+        "mixed_blank": b"\n\n>f1\nAC\n\nGT\n@q1\nAAAA\n+\nIIII\n>f2\nCC\n",
+        "long_record": b">big\n" + b"\n".join(dna(70) for _ in range(3000)) + b"\n>tail\nACGT\n",
+        "huge_line": b">one\n" + dna(40_000_000 if not gz else 400_000) + b"\n>two\nAC\n",
+    }
+    for name, data in cases.items():
+        path = tmp_path / (name + (".gz" if gz else ".txt"))
+        if gz:
+            with gzip.open(path, "wb", compresslevel=1) as f:
+                f.write(data)
+        else:
+            path.write_bytes(data)
+        out = subprocess.run([cli, "-x", "unused", "-u", str(path)], env=dict(os.environ, CFR_CLI_PARSE_ONLY="1"),
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        want = b"".join(rid + b"\t" + seq + b"\t" + (b"q:" + q if hq else b"-") + b"\n" for rid, seq, q, hq in _py_parse(data))
+        assert out == want, name
+    # pairs: two files and one interleaved file give the same records
+    m1 = b"".join(b"@p%d/1\n%s\n+\n%s\n" % (i, dna(40), b"J" * 40) for i in range(50))
+    m2 = b"".join(b"@p%d/2\n%s\n+\n%s\n" % (i, dna(45), b"J" * 45) for i in range(50))
+    (tmp_path / "m1.fq").write_bytes(m1)
+    (tmp_path / "m2.fq").write_bytes(m2)
+    r1, r2 = _py_parse(m1), _py_parse(m2)
+    inter = b"".join(b"@%s/1\n%s\n+\n%s\n@%s/2\n%s\n+\n%s\n" % (a[0], a[1], a[2], b[0], b[1], b[2]) for a, b in zip(r1, r2))
+    (tmp_path / "inter.fq").write_bytes(inter)
+    env = dict(os.environ, CFR_CLI_PARSE_ONLY="1")
+    o2 = subprocess.run([cli, "-x", "unused", "-1", str(tmp_path / "m1.fq"), "-2", str(tmp_path / "m2.fq")], env=env, check=True,
+                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    oi = subprocess.run([cli, "-x", "unused", "-i", str(tmp_path / "inter.fq")], env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    want = b"".join(a[0] + b"\t" + a[1] + b"\t" + b[1] + b"\tq:" + a[2] + b"\n" for a, b in zip(r1, r2))
+    assert o2 == want and oi == want
