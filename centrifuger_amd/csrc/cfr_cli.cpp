@@ -341,10 +341,14 @@ int main(int argc, char *argv[]) {
   if (!opt.cl_prefix.empty()) cl.open(opt.cl_prefix, paired);
   fputs(cfr_tsv_header(), stdout);
 
-  // ---- pipeline: reader -> device workers (one per GPU) -> ordered writer (this thread)
+  // ---- pipeline: reader -> dust -> device workers (one per GPU) -> TSV formatter -> ordered writer (this thread)
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<std::shared_ptr<Batch>> pending;      // parsed, waiting for a device
+  std::deque<std::shared_ptr<Batch>> pending;      // parsed, waiting for the dust stage
+  std::deque<std::shared_ptr<Batch>> dusted;       // masked, waiting for a device
+  std::deque<std::shared_ptr<Batch>> classified_q; // classified, waiting for the TSV formatter
+  bool dust_done = false;
+  size_t workers_finished = 0;
   std::deque<std::shared_ptr<Batch>> in_order;     // every batch in input order, for the writer
   std::deque<std::shared_ptr<Batch>> recycled;     // written out; their buffers serve the next batches
   bool reader_done = false;
@@ -407,7 +411,33 @@ int main(int argc, char *argv[]) {
     cv.notify_all();
   });
 
-  // ---- index load and device image, while the reader thread already parses the first batches
+  // dust stage (CentrifugerClass.cpp:276-316): needs no index either
+  std::thread duster([&]() {
+    for (;;) {
+      std::shared_ptr<Batch> b;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !pending.empty() || reader_done; });
+        if (pending.empty()) break;
+        b = pending.front();
+        pending.pop_front();
+      }
+      const auto ts = tick();
+      if (opt.dust) {
+        cfr_dust_mask_batch(b->bases1.data(), b->offs1.data(), b->n, opt.threads);
+        if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data(), b->n, opt.threads);
+      }
+      clk.add(T_DUST, ts);
+      std::lock_guard<std::mutex> lk(mu);
+      dusted.push_back(b);
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    dust_done = true;
+    cv.notify_all();
+  });
+
+  // ---- index load and device image, while the reader and dust threads already work on the first batches
   auto t0 = tick();
   cfr_index *idx = nullptr;
   cfr_status st = cfr_index_open(opt.idx.c_str(), &opt.params, &idx);
@@ -436,23 +466,18 @@ int main(int argc, char *argv[]) {
   clk.add(T_DEVICE, t0);
 
 
+  // device stage: one thread per GPU takes dust-masked batches
   auto worker = [&](cfr_dev_index *dev) {
     for (;;) {
       std::shared_ptr<Batch> b;
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&]() { return !pending.empty() || reader_done; });
-        if (pending.empty()) return;
-        b = pending.front();
-        pending.pop_front();
+        cv.wait(lk, [&]() { return !dusted.empty() || dust_done; });
+        if (dusted.empty()) break;
+        b = dusted.front();
+        dusted.pop_front();
       }
-      auto ts = tick();
-      if (opt.dust) {   // CentrifugerClass.cpp:276-316
-        cfr_dust_mask_batch(b->bases1.data(), b->offs1.data(), b->n, opt.threads);
-        if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data(), b->n, opt.threads);
-      }
-      clk.add(T_DUST, ts);
-      ts = tick();
+      const auto ts = tick();
       b->results.resize(b->n);
       size_t cap = b->n * (size_t)(opt.params.max_result > 0 ? opt.params.max_result : 4) + 16, used = 0;
       for (;;) {
@@ -464,8 +489,29 @@ int main(int argc, char *argv[]) {
         break;
       }
       clk.add(T_CLASSIFY, ts);
-      ts = tick();
-      // TSV rows (ResultWriter::Output), formatted in parallel slices then concatenated in order
+      std::lock_guard<std::mutex> lk(mu);
+      classified_q.push_back(b);
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    ++workers_finished;
+    cv.notify_all();
+  };
+  std::vector<std::thread> workers;
+  for (cfr_dev_index *d : devs) workers.emplace_back(worker, d);
+
+  // format stage: TSV rows (ResultWriter::Output), formatted in parallel slices then concatenated in order
+  std::thread formatter([&]() {
+    for (;;) {
+      std::shared_ptr<Batch> b;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&]() { return !classified_q.empty() || workers_finished == devs.size(); });
+        if (classified_q.empty()) return;
+        b = classified_q.front();
+        classified_q.pop_front();
+      }
+      const auto ts = tick();
       const int nt = (int)std::min<size_t>((size_t)opt.threads, std::max<size_t>(1, b->n / 4096));
       std::vector<std::string> parts((size_t)nt);
       auto fmt = [&](int t) {
@@ -494,9 +540,7 @@ int main(int argc, char *argv[]) {
       b->done = true;
       cv.notify_all();
     }
-  };
-  std::vector<std::thread> workers;
-  for (cfr_dev_index *d : devs) workers.emplace_back(worker, d);
+  });
 
   size_t total = 0, classified = 0;
   for (;;) {
@@ -528,7 +572,9 @@ int main(int argc, char *argv[]) {
     recycled.push_back(b);
   }
   reader.join();
+  duster.join();
   for (auto &w : workers) w.join();
+  formatter.join();
   un.close();
   cl.close();
   fflush(stdout);

@@ -15,3 +15,14 @@ for t in 16 64; do
 done
 cat gpurun_out/cli_timing.txt
 python -c "import json;d=json.loads(open('gpurun_out/cli_bench.json').read().strip().splitlines()[-1]);print(d['value'],d.get('parity'),d.get('e2e_cli'))"
+# 10 M reads (the sample five times): the stages overlap, so the wall clock approaches the slowest stage
+big=/tmp/big10m.fa
+for i in 1 2 3 4 5; do cat $fa; done > $big
+echo "== 10 M reads, -t 64" | tee -a gpurun_out/cli_timing.txt
+( time CFR_CLI_TIMING=1 centrifuger_amd/bin/centrifuger -x $idx -u $big -t 64 > /tmp/cli_big.tsv ) 2>&1 | grep -E "timing|real" | tee -a gpurun_out/cli_timing.txt
+md5sum /tmp/cli_big.tsv | tee -a gpurun_out/cli_timing.txt
+if [ -x oracle/_ref/centrifuger ]; then
+  echo "== 10 M reads, reference -t $(nproc)" | tee -a gpurun_out/cli_timing.txt
+  ( time oracle/_ref/centrifuger -x $idx -u $big -t $(nproc) > /tmp/ref_big.tsv 2>/dev/null ) 2>&1 | grep real | tee -a gpurun_out/cli_timing.txt
+  md5sum /tmp/ref_big.tsv | tee -a gpurun_out/cli_timing.txt
+fi
