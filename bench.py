@@ -348,10 +348,12 @@ def main():
     bytes_locate = cnt.locate_bytes() / ns
     locate_ms = float(np.mean([s.locate_ms for s in kstats]))
     ach = bytes_search * args.reads / (search_ms / 1e3) / 1e9
-    traffic = None
+    traffic = requests = None
     try:   # HBM/fabric bytes from the PMC passes of the same kernel (tools/pmc_passes.sh -> profiles/pmc_latest.json), scaled per read
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))["k_search_chains_v2"]
+        pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+        pm = pmj["k_search_chains_v2"]
         traffic = (pm["fabric_read_bytes_per_read"] + pm["write_bytes_per_read"]) * args.reads
+        requests = pm["TCC_EA0_RDREQ"] / pmj["reads_in_profiled_launch"] * args.reads
     except Exception:
         pass
     out["roofline"] = {
@@ -359,7 +361,13 @@ def main():
         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
         "algorithmic_bytes_per_read": bytes_search, "kernel_ms": search_ms,
         "per": "one step = the launches of the step's sub-batches (achieved, traffic and kernel_ms are all summed over them)",
-        "gather_ceiling": "tools/gather_bench: 53-55 G dependent 64-byte record fetches/s on this chip; this kernel issues ~153 fabric requests/read",
+        # the same kernel priced on what it really moves (PMC), and against the measured random-gather ceiling of the chip
+        "traffic_frac": (traffic / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "gather": ({"requests_per_s": requests / (search_ms / 1e3), "ceiling_per_s": 54e9,
+                    "frac": requests / (search_ms / 1e3) / 54e9,
+                    "note": "64-byte fabric read requests of the kernel (PMC TCC_EA0_RDREQ, SE cfg2 profile, scaled per read) per second over "
+                            "tools/gather_bench's measured ceiling for dependent random 64-byte gathers on this chip (53-55 G/s = 3.5 TB/s)"}
+                   if requests else None),
         "note": "achieved = reference-algorithm bytes (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, read bytes, 32 B/hit; counted by the "
                 "C oracle on a sample) / kernel time (HIP events on the library stream); the flat occ layout touches far fewer bytes",
         "second_kernel": {"kernel": "k_locate", "algorithmic_bytes_per_read": bytes_locate, "kernel_ms": locate_ms,
