@@ -23,7 +23,7 @@ constexpr int kBlock = 256;
 inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
 
 enum Slot : size_t {
-  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
+  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN2, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
   S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
@@ -68,6 +68,9 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   for (auto &e : tail_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_CHECK(hipStreamCreateWithFlags(&post_stream_, hipStreamNonBlocking));
+  if (const char *e = getenv("CFR_OVERLAP")) overlap_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -333,6 +336,8 @@ DeviceIndex::~DeviceIndex() {
   for (auto &set : evs_) for (auto &e : set) if (e) (void)hipEventDestroy(e);
   for (auto &e : tail_done_) if (e) (void)hipEventDestroy(e);
   for (auto &e : copy_done_) if (e) (void)hipEventDestroy(e);
+  for (auto &e : search_done_) if (e) (void)hipEventDestroy(e);
+  if (post_stream_) (void)hipStreamDestroy(post_stream_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -426,10 +431,11 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 }
 
 // search -> adjust/select -> compact -> (enumerate rows -> locate).  Two small D2H syncs (hit and row totals)
-// size the dense arrays; everything else stays on the device.
-void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                    uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
-                                    bool fused) {
+// size the dense arrays; everything else stays on the device.  Two halves so that classify_device can run the second
+// half of sub-batch k (post stream) under the search of sub-batch k+1 (main stream): launch_search owns the buffers of
+// parity `par`, launch_post everything behind the search kernel.
+DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                                  uint64_t total1, uint64_t total2, int par) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -437,17 +443,12 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
   const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
 
-  uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
-  uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
-  cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
-  uint32_t *chain_cnt = (uint32_t *)scratch(S_CHAINCNT, nchains * 4);
-  cfr_hit *fin = (cfr_hit *)scratch(S_FIN, cap_total * sizeof(cfr_hit));
-  uint64_t *fin_cnt = (uint64_t *)scratch(S_FINCNT, (n + 1) * 8);
-  uint64_t *fin_rows = (uint64_t *)scratch(S_FINROWS, cap_total * 8);
-  uint64_t *fin_off = (uint64_t *)scratch(S_FINOFF, (n + 1) * 8);
-  size_t tmp_bytes = std::max(scan_tmp_bytes(n), scan_tmp_bytes(cap_total));
+  uint64_t *cap = (uint64_t *)scratch(par ? S_CAP1 : S_CAP, (n + 1) * 8);
+  uint64_t *hit_off = (uint64_t *)scratch(par ? S_HITOFF1 : S_HITOFF, (n + 1) * 8);
+  cfr_hit *raw = (cfr_hit *)scratch(par ? S_RAW1 : S_RAW, cap_total * sizeof(cfr_hit));
+  uint32_t *chain_cnt = (uint32_t *)scratch(par ? S_CHAINCNT1 : S_CHAINCNT, nchains * 4);
+  size_t tmp_bytes = scan_tmp_bytes(n);
   void *tmp = scratch(S_SCAN, tmp_bytes);
-  uint64_t *totals = (uint64_t *)pinned(2 * 8);
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
   HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
@@ -473,70 +474,97 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
-  HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, stream_));
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
+}
+
+void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                              bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st) {
+  const bool paired = d_b2 != nullptr;
+  const size_t nchains = n * (size_t)(paired ? 4 : 2);
+  const uint64_t cap_total = sb.cap_total;
+  uint64_t *hit_off = sb.hit_off;
+  cfr_hit *raw = sb.raw;
+  uint32_t *chain_cnt = sb.chain_cnt;
+  cfr_hit *fin = (cfr_hit *)scratch(S_FIN, cap_total * sizeof(cfr_hit));
+  uint64_t *fin_cnt = (uint64_t *)scratch(S_FINCNT, (n + 1) * 8);
+  uint64_t *fin_rows = (uint64_t *)scratch(S_FINROWS, cap_total * 8);
+  uint64_t *fin_off = (uint64_t *)scratch(S_FINOFF, (n + 1) * 8);
+  size_t tmp_bytes = std::max(scan_tmp_bytes(n), scan_tmp_bytes(cap_total));
+  void *tmp = scratch(S_SCAN2, tmp_bytes);
+  uint64_t *totals = (uint64_t *)pinned(2 * 8);
+  HIP_CHECK(hipEventRecord(ev_[8], st));
+  HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, st));
   uint64_t *read_rows = fused ? (uint64_t *)scratch(S_READROWS, (n + 1) * 8) : nullptr;
-  if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
-  else k_adjust_select<2><<<grid_for(n), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
+  if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, st>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
+  else k_adjust_select<2><<<grid_for(n), kBlock, 0, st>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
   HIP_CHECK(hipGetLastError());
   if (fused) {
     // per-read row bases; one 8-byte sync sizes the tail's scratch
     uint64_t *read_row_off = (uint64_t *)scratch(S_READROWOFF, (n + 1) * 8);
-    HIP_CHECK(hipMemsetAsync(read_rows + n, 0, 8, stream_));
-    exclusive_scan(tmp, tmp_bytes, read_rows, read_row_off, n, stream_);
-    HIP_CHECK(hipEventRecord(ev_[3], stream_));
-    HIP_CHECK(hipMemcpyAsync(&totals[1], read_row_off + n, 8, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipMemsetAsync(read_rows + n, 0, 8, st));
+    exclusive_scan(tmp, tmp_bytes, read_rows, read_row_off, n, st);
+    HIP_CHECK(hipEventRecord(ev_[3], st));
+    HIP_CHECK(hipMemcpyAsync(&totals[1], read_row_off + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
     const uint64_t nrows_f = totals[1];
     uint64_t *vals_f = (uint64_t *)scratch(S_ROWVALS, (nrows_f + 1) * 8);
-    HIP_CHECK(hipEventRecord(ev_[4], stream_));
-    HIP_CHECK(hipEventRecord(ev_[5], stream_));
-    HIP_CHECK(hipEventRecord(ev_[6], stream_));
+    HIP_CHECK(hipEventRecord(ev_[4], st));
+    HIP_CHECK(hipEventRecord(ev_[5], st));
+    HIP_CHECK(hipEventRecord(ev_[6], st));
     p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f};
     last_stats.n_chains += nchains;
     last_stats.n_rows += nrows_f;
     return;
   }
-  exclusive_scan(tmp, tmp_bytes, fin_cnt, fin_off, n, stream_);
-  HIP_CHECK(hipEventRecord(ev_[3], stream_));
-  HIP_CHECK(hipMemcpyAsync(&totals[0], fin_off + n, 8, hipMemcpyDeviceToHost, stream_));
+  exclusive_scan(tmp, tmp_bytes, fin_cnt, fin_off, n, st);
+  HIP_CHECK(hipEventRecord(ev_[3], st));
+  HIP_CHECK(hipMemcpyAsync(&totals[0], fin_off + n, 8, hipMemcpyDeviceToHost, st));
   if (hit_begin_host) {
     hit_begin_host->resize(n + 1);
-    HIP_CHECK(hipMemcpyAsync(hit_begin_host->data(), fin_off, (n + 1) * 8, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(hit_begin_host->data(), fin_off, (n + 1) * 8, hipMemcpyDeviceToHost, st));
   }
-  HIP_CHECK(hipStreamSynchronize(stream_));
+  HIP_CHECK(hipStreamSynchronize(st));
   const uint64_t nhits = totals[0];
 
   cfr_hit *hits = (cfr_hit *)scratch(S_HITS, (nhits + 1) * sizeof(cfr_hit));
   uint64_t *rows_per = (uint64_t *)scratch(S_ROWSPER, (nhits + 1) * 8);
   uint64_t *row_off = (uint64_t *)scratch(S_ROWOFF, (nhits + 1) * 8);
-  k_compact_hits<<<grid_for(n), kBlock, 0, stream_>>>(n, hit_off, fin_off, fin, fin_rows, hits, rows_per);
+  k_compact_hits<<<grid_for(n), kBlock, 0, st>>>(n, hit_off, fin_off, fin, fin_rows, hits, rows_per);
   HIP_CHECK(hipGetLastError());
   uint64_t nrows = 0;
   uint64_t *rows = nullptr, *vals = nullptr;
-  HIP_CHECK(hipEventRecord(ev_[4], stream_));
+  HIP_CHECK(hipEventRecord(ev_[4], st));
   if (want_rows) {
-    HIP_CHECK(hipMemsetAsync(rows_per + nhits, 0, 8, stream_));
+    HIP_CHECK(hipMemsetAsync(rows_per + nhits, 0, 8, st));
     tmp_bytes = std::max(tmp_bytes, scan_tmp_bytes(nhits));
-    tmp = scratch(S_SCAN, tmp_bytes);
-    exclusive_scan(tmp, tmp_bytes, rows_per, row_off, nhits, stream_);
-    HIP_CHECK(hipMemcpyAsync(&totals[1], row_off + nhits, 8, hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
+    tmp = scratch(S_SCAN2, tmp_bytes);
+    exclusive_scan(tmp, tmp_bytes, rows_per, row_off, nhits, st);
+    HIP_CHECK(hipMemcpyAsync(&totals[1], row_off + nhits, 8, hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
     nrows = totals[1];
     rows = (uint64_t *)scratch(S_ROWS, (nrows + 1) * 8);
     vals = (uint64_t *)scratch(S_ROWVALS, (nrows + 1) * 8);
-    if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, stream_>>>(view_, nhits, hits, row_off, rows);
+    if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, st>>>(view_, nhits, hits, row_off, rows);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(ev_[5], stream_));
-    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, stream_>>>(view_, rows, nrows, vals, nullptr);
+    HIP_CHECK(hipEventRecord(ev_[5], st));
+    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, st>>>(view_, rows, nrows, vals, nullptr);
     HIP_CHECK(hipGetLastError());
   } else {
-    HIP_CHECK(hipEventRecord(ev_[5], stream_));
+    HIP_CHECK(hipEventRecord(ev_[5], st));
   }
-  HIP_CHECK(hipEventRecord(ev_[6], stream_));
+  HIP_CHECK(hipEventRecord(ev_[6], st));
   p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows};
   last_stats.n_chains += nchains;
   last_stats.n_hits += nhits;
   last_stats.n_rows += nrows;
+}
+
+
+void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                    uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
+                                    bool fused) {
+  const SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0);
+  launch_post(sb, d_b1, d_o1, d_b2, d_o2, n, want_rows, p, hit_begin_host, fused, stream_);
 }
 
 // 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
@@ -558,7 +586,7 @@ void DeviceIndex::finish_stats(bool want_rows) {
   auto ms = [&](int a, int b) { float t = 0; (void)hipEventElapsedTime(&t, ev_[a], ev_[b]); return t; };
   last_stats.pack_ms += ms(0, 1);
   last_stats.search_ms += ms(1, 2);
-  last_stats.adjust_ms += ms(2, 3);
+  last_stats.adjust_ms += ms(8, 3);
   last_stats.rows_ms += want_rows ? ms(4, 5) : 0.f;
   last_stats.locate_ms += want_rows ? ms(5, 6) : 0.f;
   last_stats.tail_ms += ms(6, 7);
@@ -638,37 +666,61 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     pieces.emplace_back(lo, rem);
   }
   const size_t nsub = pieces.size();
-  for (size_t k = 0; k < nsub; ++k) {
+  const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;
+  // overlapped form: the search of piece k+1 (main stream, persistent grid) runs while adjust/tail of piece k use the
+  // wave slots it leaves free (post stream); the search-side buffers alternate by parity
+  hipStream_t pst = overlap_ ? post_stream_ : stream_;
+  const uint8_t *pb2 = d_b2;
+  auto search_piece = [&](size_t k) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
     ev_ = evs_[k];
+    if (overlap_ && k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));   // piece k-2 has released these buffers
+    const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, pb2, pb2 ? d_o2 + lo : nullptr, cnt, total1, total2, overlap_ ? par : 0);
+    if (overlap_) HIP_CHECK(hipEventRecord(search_done_[par], stream_));
+    return sbuf;
+  };
+  SearchBuf sbufs[2];
+  sbufs[0] = search_piece(0);
+  for (size_t k = 0; k < nsub; ++k) {
+    const size_t lo = pieces[k].first, cnt = pieces[k].second;
+    const int par = (int)(k & 1);
+    if (overlap_ && k + 1 < nsub) sbufs[(k + 1) & 1] = search_piece(k + 1);
+    ev_ = evs_[k];
     Pipe p;
-    const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;
-    run_device_stages(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr, fused);
+    if (overlap_) HIP_CHECK(hipStreamWaitEvent(pst, search_done_[par], 0));
+    launch_post(sbufs[overlap_ ? par : 0], d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, true, p, nullptr, fused, pst);
     const uint64_t extent = stride ? stride * cnt : p.nrows;
     if (!stride) {
       if (match_extent) *match_extent = extent;
-      if (extent > match_cap) { HIP_CHECK(hipStreamSynchronize(stream_)); throw CapacityError{"match buffer too small"}; }
+      if (extent > match_cap) { HIP_CHECK(hipStreamSynchronize(stream_)); HIP_CHECK(hipStreamSynchronize(pst)); throw CapacityError{"match buffer too small"}; }
     }
     TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
     cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
     cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
-    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
-    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
-                                                                  p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
-    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
+    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(pst, copy_done_[par], 0));      // the copy that read this buffer pair
+    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, pst>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
                                                               p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
+    else k_tail<false><<<grid_for(cnt), kBlock, 0, pst>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
+                                                          p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(ev_[7], stream_));
-    HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
+    HIP_CHECK(hipEventRecord(ev_[7], pst));
+    HIP_CHECK(hipEventRecord(tail_done_[par], pst));
     HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
     HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
     if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
+    if (!overlap_ && k + 1 < nsub) sbufs[0] = search_piece(k + 1);
   }
+  HIP_CHECK(hipStreamSynchronize(pst));
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
   for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+  {  // the pieces overlap: total = first event to last event
+    float t = 0;
+    (void)hipEventElapsedTime(&t, evs_[0][0], evs_[nsub - 1][7]);
+    last_stats.total_ms = t;
+  }
   ev_ = evs_[0];
 }
 

@@ -136,6 +136,11 @@ class DeviceIndex {
   void run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                          uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
                          bool fused = false);
+  struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
+  SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                          uint64_t total1, uint64_t total2, int par);
+  void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                   bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
@@ -150,15 +155,15 @@ class DeviceIndex {
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;
   static constexpr size_t kMaxSub = 16;
-  hipEvent_t evs_[kMaxSub][8] = {};
+  hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 search side, 8 + 3-7 post side
   hipEvent_t *ev_ = nullptr;
-  hipStream_t copy_stream_ = nullptr;
-  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
+  hipStream_t copy_stream_ = nullptr, post_stream_ = nullptr;
+  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, search_done_[2] = {};
   size_t sub_batch_ = 2500000, taper_floor_ = 262144;
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
-  bool search_v1_ = false, fused_tail_ = true;
+  bool search_v1_ = false, fused_tail_ = true, overlap_ = false;
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
 };
