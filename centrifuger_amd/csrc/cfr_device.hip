@@ -460,7 +460,16 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     else k_search_chains<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
   } else {
     // persistent grid: every lane walks chains gid, gid + T, ... (T = resident lanes), see k_search_chains_v2
-    const unsigned blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * blocks_per_cu_));
+    // resident blocks only: a block that had to wait for a slot would start its share of the chains late
+    int resident = blocks_per_cu_;
+    {
+      int occ = 0;
+      const hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<4, false>, kBlock, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<2, false>, kBlock, 0);
+      if (e == hipSuccess && occ > 0) resident = std::min(resident, occ);
+      else (void)hipGetLastError();
+    }
+    const unsigned blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * resident));
     SearchView sv;
     sv.n = view_.n; sv.first_isa = view_.first_isa;
     for (int c = 0; c < 4; ++c) sv.C[c] = view_.C[c];
@@ -469,6 +478,18 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
+    if (getenv("CFR_SEARCH_PROF") && !paired) {
+      // diagnostic: iteration mix of the state machine for this launch, on stderr
+      unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
+      HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * 8, stream_));
+      k_search_chains_v2<2, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt, d_prof);
+      HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 16 * 8, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "isa", "lane_iterations", "ext_two_records", "text_rows", "block_loads"};
+      fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
+      for (int q = 0; q < 11; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
+      fprintf(stderr, " (per read)\n");
+    } else
     if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
     else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
   }
@@ -569,16 +590,19 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
 
 // 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
 void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2) {
-  nblk1_ = (total1 + 15) / 16;
-  packed1_ = (uint64_t *)scratch(S_PACK1, (nblk1_ + 2) * 8);
-  if (nblk1_) k_pack_reads<<<grid_for(nblk1_), kBlock, 0, stream_>>>(d_b1, total1, nblk1_, packed1_);
+  // 4 zero blocks ("not a symbol") in front of and behind the packed form: the search kernel fetches block pairs
+  auto pack_one = [&](size_t slot, const uint8_t *d_b, uint64_t total, uint64_t &nblk) -> uint64_t * {
+    nblk = (total + 15) / 16;
+    uint64_t *base = (uint64_t *)scratch(slot, (nblk + 8) * 8);
+    HIP_CHECK(hipMemsetAsync(base, 0, 4 * 8, stream_));
+    HIP_CHECK(hipMemsetAsync(base + 4 + nblk, 0, 4 * 8, stream_));
+    if (nblk) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(d_b, total, nblk, base + 4);
+    return base + 4;
+  };
+  packed1_ = pack_one(S_PACK1, d_b1, total1, nblk1_);
   nblk2_ = 0;
   packed2_ = nullptr;
-  if (d_b2) {
-    nblk2_ = (total2 + 15) / 16;
-    packed2_ = (uint64_t *)scratch(S_PACK2, (nblk2_ + 2) * 8);
-    if (nblk2_) k_pack_reads<<<grid_for(nblk2_), kBlock, 0, stream_>>>(d_b2, total2, nblk2_, packed2_);
-  }
+  if (d_b2) packed2_ = pack_one(S_PACK2, d_b2, total2, nblk2_);
   HIP_CHECK(hipGetLastError());
 }
 
