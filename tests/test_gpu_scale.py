@@ -1,0 +1,157 @@
+"""Size-independent properties of the HIP path on a mid-size workload (100 Mbp index written on the box by
+centrifuger_amd.indexbuild, 1 M x 150 bp reads + pairs + long reads): what must hold whatever the batch looks like -
+permutation equivariance, independence of how a batch is cut (host batches, shards, device sub-batches), determinism -
+plus agreement with the C oracle on random subsamples.  bench.py covers BASELINE's full size (1 Gbp, 10 M reads) with a
+byte comparison against the reference binary on 2 M reads.  Bit-exact everywhere.  -m gpu only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ora
+from centrifuger_amd import capi, shard, synth
+
+pytestmark = pytest.mark.gpu
+N_READS = 1_000_000
+READ_LEN = 150
+
+
+def canon(results, matches, k):
+    """(n, 5) scalar fields and (n, k, 3) match slots with match_begin resolved (order inside a read is part of the result)."""
+    n = len(results)
+    sc = np.stack([results["score"].astype(np.int64), results["secondary_score"].astype(np.int64), results["hit_length"].astype(np.int64),
+                   results["query_length"].astype(np.int64), results["n_match"].astype(np.int64)], axis=1)
+    slots = np.zeros((n, k, 3), dtype=np.int64)
+    nm = results["n_match"].astype(np.int64)
+    mb = results["match_begin"].astype(np.int64)
+    for q in range(k):
+        live = nm > q
+        src = matches[np.where(live, mb + q, 0)]
+        slots[:, q, 0] = np.where(live, src["id"].astype(np.int64), 0)
+        slots[:, q, 1] = np.where(live, src["taxid"].astype(np.int64), 0)
+        slots[:, q, 2] = np.where(live, src["kind"].astype(np.int64), 0)
+    return sc, slots
+
+
+def digest(sc, slots):
+    return hashlib.md5(sc.tobytes() + slots.tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def world(tmp_path_factory):
+    import torch
+    d = str(tmp_path_factory.mktemp("scale"))
+    g = synth.make_genomes(25, 4, 1_000_000, seed=4242)
+    from centrifuger_amd import indexbuild
+    prefix = os.path.join(d, "idx")
+    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    reads = synth.make_reads(g, N_READS, READ_LEN, seed=77, sub_rate=0.01, n_rate=0.001)
+    r1, r2 = synth.make_pairs(g, 200_000, 125, seed=78)
+    longs = synth.make_long_reads(g, 3000, 2000, 12000, seed=79)
+    return {"prefix": prefix, "reads": reads, "pairs": (r1, r2), "long": longs}
+
+
+def _open(prefix, k, env=None):
+    old = {}
+    for key, val in (env or {}).items():
+        old[key] = os.environ.get(key)
+        os.environ[key] = val
+    try:
+        idx = capi.Index(prefix, capi.default_params(max_result=k))
+        dev = capi.DeviceIndex(idx)
+    finally:
+        for key, val in old.items():
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
+    return idx, dev
+
+
+def test_permutation_cut_and_determinism_single_end(world):
+    k = 3
+    rs = world["reads"]
+    idx, dev = _open(world["prefix"], k)
+    res, mat = dev.classify(rs.bases, rs.offsets)
+    sc, slots = canon(res, mat, k)
+    assert (res["n_match"] > 0).mean() > 0.99
+    # determinism: the same call again
+    res2, mat2 = dev.classify(rs.bases, rs.offsets)
+    assert digest(*canon(res2, mat2, k)) == digest(sc, slots)
+    # permutation equivariance
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(N_READS)
+    pb = rs.bases.reshape(N_READS, READ_LEN)[perm].reshape(-1)
+    resp, matp = dev.classify(pb, rs.offsets)
+    scp, slotsp = canon(resp, matp, k)
+    assert np.array_equal(scp, sc[perm]) and np.array_equal(slotsp, slots[perm])
+    # how the batch is cut does not matter: 3 unequal host batches, 5 shards (centrifuger_amd.shard), tiny device sub-batches
+    cuts = [0, 123_457, 700_001, N_READS]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        o = rs.offsets[lo:hi + 1]
+        parts.append(dev.classify(rs.bases[int(o[0]):int(o[-1])], (o - o[0]).astype(np.uint64)))
+    resm, matm = shard.merge_results(parts)
+    assert digest(*canon(resm, matm, k)) == digest(sc, slots)
+    parts = [dev.classify(*shard.shard_reads(rs.bases, rs.offsets, 5, r)) for r in range(5)]
+    resm, matm = shard.merge_results(parts)
+    assert digest(*canon(resm, matm, k)) == digest(sc, slots)
+    dev.close()
+    idx2, dev2 = _open(world["prefix"], k, {"CFR_SUBBATCH": "33333", "CFR_TAPER_FLOOR": "1000"})
+    res3, mat3 = dev2.classify(rs.bases, rs.offsets)
+    assert digest(*canon(res3, mat3, k)) == digest(sc, slots)
+    dev2.close()
+    # without any derived table (plain FM-index walk on the flat image) the same answers again
+    idx3, dev3 = _open(world["prefix"], k, {"CFR_FTABX_WIDTH": "0", "CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0"})
+    res4, mat4 = dev3.classify(rs.bases, rs.offsets)
+    assert digest(*canon(res4, mat4, k)) == digest(sc, slots)
+    dev3.close()
+    # oracle on a random subsample
+    o = ora.OracleIndex(world["prefix"], max_result=k)
+    pick = np.sort(rng.choice(N_READS, size=4000, replace=False))
+    sb = rs.bases.reshape(N_READS, READ_LEN)[pick].reshape(-1)
+    so = (np.arange(len(pick) + 1, dtype=np.uint64) * np.uint64(READ_LEN))
+    ores = o.classify(sb, so, threads=16)
+    for j, i in enumerate(pick):
+        assert idx.format_tsv("r", res[i], mat) == o.format("r", ores[j]), int(i)
+    o.close()
+
+
+def test_pairs_and_long_reads_against_oracle_and_cuts(world):
+    k = 5
+    idx, dev = _open(world["prefix"], k)
+    r1, r2 = world["pairs"]
+    n = len(r1.offsets) - 1
+    res, mat = dev.classify(r1.bases, r1.offsets, r2.bases, r2.offsets)
+    half = n // 2 + 17
+    parts = []
+    for lo, hi in ((0, half), (half, n)):
+        o1, o2 = r1.offsets[lo:hi + 1], r2.offsets[lo:hi + 1]
+        parts.append(dev.classify(r1.bases[int(o1[0]):int(o1[-1])], (o1 - o1[0]).astype(np.uint64),
+                                  r2.bases[int(o2[0]):int(o2[-1])], (o2 - o2[0]).astype(np.uint64)))
+    resm, matm = shard.merge_results(parts)
+    assert digest(*canon(resm, matm, k)) == digest(*canon(res, mat, k))
+    o = ora.OracleIndex(world["prefix"], max_result=k)
+    m = 3000
+    ores = o.classify(r1.bases[:int(r1.offsets[m])], r1.offsets[:m + 1], r2.bases[:int(r2.offsets[m])], r2.offsets[:m + 1], threads=16)
+    for i in range(m):
+        assert idx.format_tsv("p", res[i], mat) == o.format("p", ores[i]), i
+    lg = world["long"]
+    nl = len(lg.offsets) - 1
+    resl, matl = dev.classify(lg.bases, lg.offsets)
+    m = 150
+    oresl = o.classify(lg.bases[:int(lg.offsets[m])], lg.offsets[:m + 1], threads=16)
+    for i in range(m):
+        assert idx.format_tsv("l", resl[i], matl) == o.format("l", oresl[i]), i
+    # reversing the order of the long reads reverses the results
+    order = np.arange(nl)[::-1]
+    lens = np.diff(lg.offsets.astype(np.int64))
+    rb = np.concatenate([lg.bases[int(lg.offsets[i]):int(lg.offsets[i + 1])] for i in order])
+    ro = np.concatenate([[0], np.cumsum(lens[order])]).astype(np.uint64)
+    resr, matr = dev.classify(rb, ro)
+    scl, sll = canon(resl, matl, k)
+    scr, slr = canon(resr, matr, k)
+    assert np.array_equal(scr, scl[order]) and np.array_equal(slr, sll[order])
+    o.close()
+    dev.close()
