@@ -23,7 +23,7 @@ constexpr int kBlock = 256;
 inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
 
 enum Slot : size_t {
-  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN2, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
+  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
   S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
@@ -71,6 +71,8 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&post_stream_, hipStreamNonBlocking));
   if (const char *e = getenv("CFR_OVERLAP")) overlap_ = atoi(e) != 0;
+  if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
+  if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);
   if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -704,9 +706,52 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     if (overlap_) HIP_CHECK(hipEventRecord(search_done_[par], stream_));
     return sbuf;
   };
+  // one-launch post stage (k_adjust_tail): no host round trip inside a sub-batch; a sub-batch whose scratch pool ran dry
+  // is repeated through the two-kernel path below
+  const bool fused_post = fused && stride > 0 && fused_post_ && !overlap_;
+  std::vector<size_t> redo;
+  if (fused_post) {
+    const bool paired = d_b2 != nullptr;
+    uint32_t *ovf = (uint32_t *)pinned((2 + kMaxSub) * 8) + 4;      // behind the two u64 totals
+    for (size_t k = 0; k < nsub; ++k) ovf[k] = 0;
+    for (size_t k = 0; k < nsub; ++k) {
+      const size_t lo = pieces[k].first, cnt = pieces[k].second;
+      const int par = (int)(k & 1);
+      ev_ = evs_[k];
+      const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, 0);
+      for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
+      const uint64_t pool_cap = pool_cap_ ? pool_cap_ : std::max<uint64_t>(8ull * sb, 1ull << 20);
+      TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap * sizeof(TailEntry));
+      uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap * 8);
+      unsigned long long *ctl = (unsigned long long *)scratch(par ? S_POOLCTL1 : S_POOLCTL, 16);
+      cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
+      cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (stride * std::max(cnt, sb) + 1) * sizeof(cfr_match));
+      if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));   // the copies that read this buffer pair (and its ctl)
+      HIP_CHECK(hipMemsetAsync(ctl, 0, 16, stream_));
+      if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                         pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+      else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                  pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipEventRecord(ev_[7], stream_));
+      HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
+      HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
+      HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
+      HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, stride * cnt * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+      HIP_CHECK(hipMemcpyAsync(&ovf[k], ctl + 1, 4, hipMemcpyDeviceToHost, copy_stream_));
+      HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
+      last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    HIP_CHECK(hipStreamSynchronize(copy_stream_));
+    for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+    for (size_t k = 0; k < nsub; ++k) if (ovf[k]) redo.push_back(k);
+  }
   SearchBuf sbufs[2];
-  sbufs[0] = search_piece(0);
+  if (!fused_post) sbufs[0] = search_piece(0);
   for (size_t k = 0; k < nsub; ++k) {
+    if (fused_post && std::find(redo.begin(), redo.end(), k) == redo.end()) continue;
+    if (fused_post) sbufs[0] = search_piece(k);
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
     if (overlap_ && k + 1 < nsub) sbufs[(k + 1) & 1] = search_piece(k + 1);
@@ -734,13 +779,13 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
     if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
-    if (!overlap_ && k + 1 < nsub) sbufs[0] = search_piece(k + 1);
+    if (!overlap_ && !fused_post && k + 1 < nsub) sbufs[0] = search_piece(k + 1);
   }
   HIP_CHECK(hipStreamSynchronize(pst));
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
-  for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
-  {  // the pieces overlap: total = first event to last event
+  if (!fused_post) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+  if (redo.empty()) {  // the pieces may overlap: total = first event to last event
     float t = 0;
     (void)hipEventElapsedTime(&t, evs_[0][0], evs_[nsub - 1][7]);
     last_stats.total_ms = t;

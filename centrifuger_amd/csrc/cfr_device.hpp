@@ -7,8 +7,9 @@
 //                u64 lo1, hi1 bit planes of symbols 64..127
 //              => FMIndex::Rank(c, p) / Sequence::Access(p) touch exactly ONE 64-byte record:
 //                 8 B (mid[c]) + 16 B (the half that holds symbol p).
+//              Expanded ON THE DEVICE at load time from the uploaded run-block components (k_occ_expand + a scan).
 //   ftab     : (start, count) u64 pairs, 4^w entries          (FMIndex.hpp:27)
-//   ftabx    : DERIVED at load time, never on disk: for every K-mer (K = log4(n)+1, at most 16, > w) the exact state
+//   ftabx    : DERIVED at load time, never on disk: for every K-mer (K = log4(n)+2, at most 16, > w) the exact state
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
@@ -163,7 +164,8 @@ class DeviceIndex {
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
-  bool search_v1_ = false, fused_tail_ = true, overlap_ = false;
+  bool search_v1_ = false, fused_tail_ = true, overlap_ = false, fused_post_ = true;
+  uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
 };

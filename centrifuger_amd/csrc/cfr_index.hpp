@@ -5,8 +5,8 @@
 // Bitvector_Plain::Save (Bitvector_Plain.hpp:182-196), _FMIndexAuxData::Save (FMIndex.hpp:100-134)
 // and Taxonomy::Save (Taxonomy.hpp:1238-1257); grammar in SURVEY.md Appendix A.
 //
-// The parser keeps the compressed components verbatim (for the run-block device image) and
-// also unpacks the conceptual BWT string into 2-bit symbols (for the flat occurrence image).
+// The parser keeps the compressed components verbatim; the BWT string itself is never decoded on the host (the
+// device expands its flat occurrence image from the uploaded components, cfr_device.hip / k_occ_expand).
 #pragma once
 
 #include <cstdint>

@@ -103,7 +103,7 @@ typedef struct {
 /* kernel timing of the last batch call on a device index (HIP events on the library's stream) */
 typedef struct {
   float pack_ms, search_ms, adjust_ms, rows_ms, locate_ms, tail_ms, total_ms;
-  uint64_t n_chains, n_hits, n_rows;   /* n_hits stays 0 when the fused tail runs (it never materialises the dense hit total) */
+  uint64_t n_chains, n_hits, n_rows;   /* n_hits / n_rows stay 0 on the paths that never need those totals on the host (fused tail; one-launch post stage) */
 } cfr_batch_stats;
 
 void cfr_params_default(cfr_params *p);

@@ -204,5 +204,5 @@ def test_fresh_index_against_reference_binary_and_oracle(paired, k, tmp_path):
         assert (results[i]["score"], results[i]["secondary_score"], results[i]["hit_length"], results[i]["n_match"]) == \
                (ores[i].score, ores[i].secondaryScore, ores[i].hitLength, ores[i].nmatch)
     st = d.last_stats()
-    # (n_hits is only counted by the unfused pipeline: the fused tail never needs the dense hit total)
-    assert st.n_chains == n * (4 if paired else 2) and st.n_rows > 0
+    # (n_hits / n_rows are only counted by the pipelines that need those totals on the host: the one-launch post stage does not)
+    assert st.n_chains == n * (4 if paired else 2)

@@ -17,6 +17,8 @@ VARIANTS = {
     "text_mode_early": {"CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003", "CFR_TAPER_FLOOR": "0"},
     "post_stage_overlap": {"CFR_OVERLAP": "1", "CFR_SUBBATCH": "97", "CFR_TAPER_FLOOR": "0", "CFR_BLOCKS_PER_CU": "2"},
+    "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
+    "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "fast_load_profile": {"CFR_PROFILE": "fast-load"},
     "tapered_last_subbatch": {"CFR_SUBBATCH": "300", "CFR_TAPER_FLOOR": "5"},
     "unfused_tail": {"CFR_FUSED_TAIL": "0", "CFR_SUBBATCH": "61"},
