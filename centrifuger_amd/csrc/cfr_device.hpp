@@ -160,7 +160,7 @@ class DeviceIndex {
   hipEvent_t *ev_ = nullptr;
   hipStream_t copy_stream_ = nullptr, post_stream_ = nullptr;
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, search_done_[2] = {};
-  size_t sub_batch_ = 2500000, taper_floor_ = 262144;
+  size_t sub_batch_ = 1250000, taper_floor_ = 262144;
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
