@@ -23,7 +23,7 @@ constexpr int kBlock = 256;
 inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
 
 enum Slot : size_t {
-  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
+  S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
   S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
@@ -68,9 +68,6 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   for (auto &e : tail_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_CHECK(hipStreamCreateWithFlags(&post_stream_, hipStreamNonBlocking));
-  if (const char *e = getenv("CFR_OVERLAP")) overlap_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);
   if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
@@ -338,8 +335,6 @@ DeviceIndex::~DeviceIndex() {
   for (auto &set : evs_) for (auto &e : set) if (e) (void)hipEventDestroy(e);
   for (auto &e : tail_done_) if (e) (void)hipEventDestroy(e);
   for (auto &e : copy_done_) if (e) (void)hipEventDestroy(e);
-  for (auto &e : search_done_) if (e) (void)hipEventDestroy(e);
-  if (post_stream_) (void)hipStreamDestroy(post_stream_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -433,11 +428,10 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 }
 
 // search -> adjust/select -> compact -> (enumerate rows -> locate).  Two small D2H syncs (hit and row totals)
-// size the dense arrays; everything else stays on the device.  Two halves so that classify_device can run the second
-// half of sub-batch k (post stream) under the search of sub-batch k+1 (main stream): launch_search owns the buffers of
-// parity `par`, launch_post everything behind the search kernel.
+// size the dense arrays; everything else stays on the device.  Two halves: launch_search (caps, scan, the search kernel)
+// is also what the one-launch post stage of classify_device follows; launch_post is everything behind the search kernel.
 DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                                  uint64_t total1, uint64_t total2, int par) {
+                                                  uint64_t total1, uint64_t total2) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -445,10 +439,10 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
   const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
 
-  uint64_t *cap = (uint64_t *)scratch(par ? S_CAP1 : S_CAP, (n + 1) * 8);
-  uint64_t *hit_off = (uint64_t *)scratch(par ? S_HITOFF1 : S_HITOFF, (n + 1) * 8);
-  cfr_hit *raw = (cfr_hit *)scratch(par ? S_RAW1 : S_RAW, cap_total * sizeof(cfr_hit));
-  uint32_t *chain_cnt = (uint32_t *)scratch(par ? S_CHAINCNT1 : S_CHAINCNT, nchains * 4);
+  uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
+  uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
+  cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
+  uint32_t *chain_cnt = (uint32_t *)scratch(S_CHAINCNT, nchains * 4);
   size_t tmp_bytes = scan_tmp_bytes(n);
   void *tmp = scratch(S_SCAN, tmp_bytes);
 
@@ -586,7 +580,7 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
 void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                     uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
                                     bool fused) {
-  const SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0);
+  const SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2);
   launch_post(sb, d_b1, d_o1, d_b2, d_o2, n, want_rows, p, hit_begin_host, fused, stream_);
 }
 
@@ -662,7 +656,26 @@ void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const ui
 
 // Whole Query on the device.  matches: max_result > 0 -> read i owns [i*max_result, ...); otherwise the
 // read's slice of the located-row space.  *match_extent = number of match slots the caller must provide.
-// The batch is cut into sub-batches: the D2H copy of sub-batch k (copy stream) overlaps the kernels of k+1.
+// The batch is cut into sub-batches ("pieces"): the D2H copy of piece k (copy stream) overlaps the kernels of k+1.
+std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool per_read_slots, size_t &sb) const {
+  // full sub-batches, then the last one is halved down to taper_floor_ reads so that the copy left exposed after the
+  // last kernel is small; at most kMaxSub pieces (one event set each)
+  const size_t kTaperMax = 4;
+  sb = per_read_slots ? std::max(sub_batch_, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;   // row-space matches: one piece
+  std::vector<std::pair<size_t, size_t>> pieces;
+  size_t lo = 0;
+  while (n - lo > sb) { pieces.emplace_back(lo, sb); lo += sb; }
+  size_t rem = n - lo;
+  for (size_t t = 0; per_read_slots && taper_floor_ && t + 1 < kTaperMax && rem > 2 * taper_floor_; ++t) {
+    const size_t c = rem / 2;
+    pieces.emplace_back(lo, c);
+    lo += c;
+    rem -= c;
+  }
+  pieces.emplace_back(lo, rem);
+  return pieces;
+}
+
 void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
                                   size_t *match_extent) {
@@ -674,118 +687,92 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
-  // pieces: full sub-batches, then the last one is halved down to taper_floor_ reads so that the copy left exposed
-  // after the last kernel is small (every piece's D2H copy overlaps the kernels of the next one)
-  const size_t kTaperMax = 4;
-  size_t sb = stride ? std::max(sub_batch_, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;     // row-space matches: one piece
-  std::vector<std::pair<size_t, size_t>> pieces;
-  {
-    size_t lo = 0;
-    while (n - lo > sb) { pieces.emplace_back(lo, sb); lo += sb; }
-    size_t rem = n - lo;
-    for (size_t t = 0; stride && taper_floor_ && t + 1 < kTaperMax && rem > 2 * taper_floor_; ++t) {
-      const size_t c = rem / 2;
-      pieces.emplace_back(lo, c);
-      lo += c;
-      rem -= c;
-    }
-    pieces.emplace_back(lo, rem);
-  }
+  size_t sb = 0;
+  const auto pieces = cut_pieces(n, stride > 0, sb);
   const size_t nsub = pieces.size();
-  const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;
-  // overlapped form: the search of piece k+1 (main stream, persistent grid) runs while adjust/tail of piece k use the
-  // wave slots it leaves free (post stream); the search-side buffers alternate by parity
-  hipStream_t pst = overlap_ ? post_stream_ : stream_;
-  const uint8_t *pb2 = d_b2;
-  auto search_piece = [&](size_t k) {
+  const bool paired = d_b2 != nullptr;
+  const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;     // k_tail answers rows from the memo itself
+  const bool one_launch = fused && stride > 0 && fused_post_;                   // k_adjust_tail: no host round trip in a piece
+
+  // results / matches of piece k leave through the buffer pair of its parity while piece k+1 computes
+  auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
-    ev_ = evs_[k];
-    if (overlap_ && k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));   // piece k-2 has released these buffers
-    const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, pb2, pb2 ? d_o2 + lo : nullptr, cnt, total1, total2, overlap_ ? par : 0);
-    if (overlap_) HIP_CHECK(hipEventRecord(search_done_[par], stream_));
-    return sbuf;
+    HIP_CHECK(hipEventRecord(ev_[7], stream_));
+    HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
+    HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
+    HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
+    if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+    if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
+    HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   };
-  // one-launch post stage (k_adjust_tail): no host round trip inside a sub-batch; a sub-batch whose scratch pool ran dry
-  // is repeated through the two-kernel path below
-  const bool fused_post = fused && stride > 0 && fused_post_ && !overlap_;
-  std::vector<size_t> redo;
-  if (fused_post) {
-    const bool paired = d_b2 != nullptr;
+  auto out_buffers = [&](size_t k, uint64_t extent, cfr_result *&d_res, cfr_match *&d_match) {
+    const int par = (int)(k & 1);
+    d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(pieces[k].second, sb) * sizeof(cfr_result));
+    d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
+    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
+  };
+
+  // ---- one launch per piece behind the search: everything is enqueued at once
+  std::vector<size_t> todo;                 // pieces for the multi-kernel form
+  if (one_launch) {
     uint32_t *ovf = (uint32_t *)pinned((2 + kMaxSub) * 8) + 4;      // behind the two u64 totals
-    for (size_t k = 0; k < nsub; ++k) ovf[k] = 0;
+    const uint64_t pool_cap = pool_cap_ ? pool_cap_ : std::max<uint64_t>(8ull * sb, 1ull << 20);
+    TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap * sizeof(TailEntry));
+    uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap * 8);
     for (size_t k = 0; k < nsub; ++k) {
       const size_t lo = pieces[k].first, cnt = pieces[k].second;
-      const int par = (int)(k & 1);
+      ovf[k] = 0;
       ev_ = evs_[k];
-      const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, total1, total2, 0);
+      const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
       for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
-      const uint64_t pool_cap = pool_cap_ ? pool_cap_ : std::max<uint64_t>(8ull * sb, 1ull << 20);
-      TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap * sizeof(TailEntry));
-      uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap * 8);
-      unsigned long long *ctl = (unsigned long long *)scratch(par ? S_POOLCTL1 : S_POOLCTL, 16);
-      cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
-      cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (stride * std::max(cnt, sb) + 1) * sizeof(cfr_match));
-      if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));   // the copies that read this buffer pair (and its ctl)
+      unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 16);    // pool cursor, overflow flag
+      cfr_result *d_res;
+      cfr_match *d_match;
+      out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
       HIP_CHECK(hipMemsetAsync(ctl, 0, 16, stream_));
       if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                          pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
       else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                   pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
       HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipEventRecord(ev_[7], stream_));
-      HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
-      HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
-      HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
-      HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, stride * cnt * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
-      HIP_CHECK(hipMemcpyAsync(&ovf[k], ctl + 1, 4, hipMemcpyDeviceToHost, copy_stream_));
-      HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
+      copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
       last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
     }
     HIP_CHECK(hipStreamSynchronize(stream_));
     HIP_CHECK(hipStreamSynchronize(copy_stream_));
     for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
-    for (size_t k = 0; k < nsub; ++k) if (ovf[k]) redo.push_back(k);
+    for (size_t k = 0; k < nsub; ++k) if (ovf[k]) todo.push_back(k);        // scratch pool ran dry: repeat below
+  } else {
+    for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   }
-  SearchBuf sbufs[2];
-  if (!fused_post) sbufs[0] = search_piece(0);
-  for (size_t k = 0; k < nsub; ++k) {
-    if (fused_post && std::find(redo.begin(), redo.end(), k) == redo.end()) continue;
-    if (fused_post) sbufs[0] = search_piece(k);
+
+  // ---- multi-kernel form: search, adjust/select, (compact, rows, locate,) tail; one or two 8-byte host syncs per piece
+  for (size_t k : todo) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
-    const int par = (int)(k & 1);
-    if (overlap_ && k + 1 < nsub) sbufs[(k + 1) & 1] = search_piece(k + 1);
     ev_ = evs_[k];
     Pipe p;
-    if (overlap_) HIP_CHECK(hipStreamWaitEvent(pst, search_done_[par], 0));
-    launch_post(sbufs[overlap_ ? par : 0], d_b1, d_o1 + lo, d_b2, d_b2 ? d_o2 + lo : nullptr, cnt, true, p, nullptr, fused, pst);
+    run_device_stages(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr, fused);
     const uint64_t extent = stride ? stride * cnt : p.nrows;
     if (!stride) {
       if (match_extent) *match_extent = extent;
-      if (extent > match_cap) { HIP_CHECK(hipStreamSynchronize(stream_)); HIP_CHECK(hipStreamSynchronize(pst)); throw CapacityError{"match buffer too small"}; }
+      if (extent > match_cap) { HIP_CHECK(hipStreamSynchronize(stream_)); throw CapacityError{"match buffer too small"}; }
     }
     TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
-    cfr_result *d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(cnt, sb) * sizeof(cfr_result));
-    cfr_match *d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
-    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(pst, copy_done_[par], 0));      // the copy that read this buffer pair
-    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, pst>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
+    cfr_result *d_res;
+    cfr_match *d_match;
+    out_buffers(k, extent, d_res, d_match);
+    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
+                                                                  p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
+    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
                                                               p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
-    else k_tail<false><<<grid_for(cnt), kBlock, 0, pst>>>(view_, cnt, d_o1 + lo, d_b2 ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
-                                                          p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipEventRecord(ev_[7], pst));
-    HIP_CHECK(hipEventRecord(tail_done_[par], pst));
-    HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
-    HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
-    if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
-    HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
-    if (!overlap_ && !fused_post && k + 1 < nsub) sbufs[0] = search_piece(k + 1);
+    copy_out(k, d_res, d_match, extent, nullptr, nullptr);
   }
-  HIP_CHECK(hipStreamSynchronize(pst));
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
-  if (!fused_post) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
-  if (redo.empty()) {  // the pieces may overlap: total = first event to last event
+  if (!one_launch) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+  if (todo.empty() || !one_launch) {        // wall time of the device work: first event of the first piece to the last of the last
     float t = 0;
     (void)hipEventElapsedTime(&t, evs_[0][0], evs_[nsub - 1][7]);
     last_stats.total_ms = t;

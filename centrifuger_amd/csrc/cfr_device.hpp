@@ -27,6 +27,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cfr_index.hpp"
@@ -139,9 +140,10 @@ class DeviceIndex {
                          bool fused = false);
   struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
   SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                          uint64_t total1, uint64_t total2, int par);
+                          uint64_t total1, uint64_t total2);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                    bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
+  std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb) const;
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
@@ -156,15 +158,15 @@ class DeviceIndex {
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;
   static constexpr size_t kMaxSub = 16;
-  hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 search side, 8 + 3-7 post side
+  hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 around the search, 8 and 3-7 around the stages behind it
   hipEvent_t *ev_ = nullptr;
-  hipStream_t copy_stream_ = nullptr, post_stream_ = nullptr;
-  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, search_done_[2] = {};
+  hipStream_t copy_stream_ = nullptr;
+  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
   size_t sub_batch_ = 1250000, taper_floor_ = 262144;
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
-  bool search_v1_ = false, fused_tail_ = true, overlap_ = false, fused_post_ = true;
+  bool search_v1_ = false, fused_tail_ = true, fused_post_ = true;
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;

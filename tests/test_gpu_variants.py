@@ -16,7 +16,6 @@ VARIANTS = {
     "no_derived_tables": {"CFR_FTABX_WIDTH": "0", "CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0"},
     "text_mode_early": {"CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003", "CFR_TAPER_FLOOR": "0"},
-    "post_stage_overlap": {"CFR_OVERLAP": "1", "CFR_SUBBATCH": "97", "CFR_TAPER_FLOOR": "0", "CFR_BLOCKS_PER_CU": "2"},
     "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
     "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "fast_load_profile": {"CFR_PROFILE": "fast-load"},
