@@ -363,10 +363,12 @@ def main():
         "per": "one step = the launches of the step's sub-batches (achieved, traffic and kernel_ms are all summed over them)",
         # the same kernel priced on what it really moves (PMC), and against the measured random-gather ceiling of the chip
         "traffic_frac": (traffic / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        "gather": ({"requests_per_s": requests / (search_ms / 1e3), "ceiling_per_s": 54e9,
-                    "frac": requests / (search_ms / 1e3) / 54e9,
+        "gather": ({"requests_per_s": requests / (search_ms / 1e3), "ceiling_per_s": 48e9,
+                    "frac": requests / (search_ms / 1e3) / 48e9,
                     "note": "64-byte fabric read requests of the kernel (PMC TCC_EA0_RDREQ, SE cfg2 profile, scaled per read) per second over "
-                            "tools/gather_bench's measured ceiling for dependent random 64-byte gathers on this chip (53-55 G/s = 3.5 TB/s)"}
+                            "tools/gather_bench's measured ceiling for dependent random 64-byte gathers at this footprint (48 G/s = 3.1 TB/s for "
+                            "tables of 16-128 GB with one load per record, 38 G/s with two loads per record as in a BWT extend; 55 G/s below 1 GB: "
+                            "profiles/r1f_gather_bench.txt)"}
                    if requests else None),
         "note": "achieved = reference-algorithm bytes (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, read bytes, 32 B/hit; counted by the "
                 "C oracle on a sample) / kernel time (HIP events on the library stream); the flat occ layout touches far fewer bytes",
