@@ -42,6 +42,18 @@ def test_cli_gz_input_interleaved_and_batches(golden_dir, tmp_path):
     assert out == open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
 
 
+def test_cli_several_device_workers_keep_input_order(golden_dir):
+    """--gpu LIST starts one worker (and one device index) per entry; three workers on ordinal 0 race over 25-read batches and
+    the writer must still emit the reference's rows in input order.  Also the throughput profile through the command line."""
+    want = open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
+    base = [CLI, "-x", os.path.join(golden_dir, "f6"), "-1", os.path.join(golden_dir, "pe_1.fq"), "-2", os.path.join(golden_dir, "pe_2.fq"), "-k", "5"]
+    out = subprocess.run(base + ["--gpu", "0,0,0", "--gpu-batch", "25", "-t", "4"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert out == want
+    out = subprocess.run(base + ["--gpu", "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         env=dict(os.environ, CFR_PROFILE="throughput")).stdout
+    assert out == want
+
+
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
 def test_cli_read_dumps_match_reference(golden_dir, tmp_path):
     for tool, tag in ((os.path.join(REF_DIR, "centrifuger"), "ref"), (CLI, "gpu")):
