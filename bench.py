@@ -46,7 +46,7 @@ def build_index(args, cache, device=None):
         return prefix
     os.makedirs(cache, exist_ok=True)
     t0 = time.time()
-    g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed)
+    g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step)
     np.save(os.path.join(cache, "genome_cat.npy"), np.concatenate(g.seqs))
     np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum([len(s) for s in g.seqs])]).astype(np.int64))
     log(f"genomes: {g.total_len/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--species", type=int, default=50)
     ap.add_argument("--strains", type=int, default=5)
     ap.add_argument("--genome-len", type=int, default=4_000_000)
+    ap.add_argument("--divergence-step", type=float, default=0.01, help="strain k of a species differs from its base by k x this fraction of substitutions")
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed", type=int, default=20260928)
@@ -237,7 +238,7 @@ def main():
         dist.init_process_group(backend="gloo" if share_gpu else "nccl")
 
     from centrifuger_amd import capi
-    key = hashlib.md5(f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}".encode()).hexdigest()[:10]
+    key = hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")).encode()).hexdigest()[:10]
     cache = os.path.join(args.cache, key)
     if rank == 0:
         prefix = build_index(args, cache, device)

@@ -69,7 +69,8 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   for (auto &e : tail_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
-  if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);
+  if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
+  else if (const char *e2 = getenv("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
   if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -714,38 +715,45 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   };
 
   // ---- one launch per piece behind the search: everything is enqueued at once
-  std::vector<size_t> todo;                 // pieces for the multi-kernel form
+  std::vector<size_t> todo;                 // pieces still to do
+  for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
     uint32_t *ovf = (uint32_t *)pinned((2 + kMaxSub) * 8) + 4;      // behind the two u64 totals
-    const uint64_t pool_cap = pool_cap_ ? pool_cap_ : std::max<uint64_t>(8ull * sb, 1ull << 20);
-    TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap * sizeof(TailEntry));
-    uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap * 8);
-    for (size_t k = 0; k < nsub; ++k) {
-      const size_t lo = pieces[k].first, cnt = pieces[k].second;
-      ovf[k] = 0;
-      ev_ = evs_[k];
-      const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
-      for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
-      unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 16);    // pool cursor, overflow flag
-      cfr_result *d_res;
-      cfr_match *d_match;
-      out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
-      HIP_CHECK(hipMemsetAsync(ctl, 0, 16, stream_));
-      if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                         pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-      else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                  pool_e, pool_v, ctl, pool_cap, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-      HIP_CHECK(hipGetLastError());
-      copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
-      last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
+    if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
+    const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
+    for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
+      TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap_ * sizeof(TailEntry));
+      uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap_ * 8);
+      for (size_t k : todo) {
+        const size_t lo = pieces[k].first, cnt = pieces[k].second;
+        ovf[k] = 0;
+        ev_ = evs_[k];
+        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
+        for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
+        unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 16);    // pool cursor, overflow flag
+        cfr_result *d_res;
+        cfr_match *d_match;
+        out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
+        HIP_CHECK(hipMemsetAsync(ctl, 0, 16, stream_));
+        if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                           pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+        else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                    pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+        HIP_CHECK(hipGetLastError());
+        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
+        if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
+      }
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      HIP_CHECK(hipStreamSynchronize(copy_stream_));
+      if (attempt == 0) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+      std::vector<size_t> again;
+      for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
+      todo.swap(again);
+      if (todo.empty() || pool_cap_ >= pool_limit || getenv("CFR_POOL_CAP")) break;
+      pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it
     }
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    HIP_CHECK(hipStreamSynchronize(copy_stream_));
-    for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
-    for (size_t k = 0; k < nsub; ++k) if (ovf[k]) todo.push_back(k);        // scratch pool ran dry: repeat below
-  } else {
-    for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   }
+  const bool repeated = one_launch && !todo.empty();
 
   // ---- multi-kernel form: search, adjust/select, (compact, rows, locate,) tail; one or two 8-byte host syncs per piece
   for (size_t k : todo) {
@@ -772,7 +780,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
   if (!one_launch) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
-  if (todo.empty() || !one_launch) {        // wall time of the device work: first event of the first piece to the last of the last
+  if (!repeated) {                          // wall time of the device work: first event of the first piece to the last of the last
     float t = 0;
     (void)hipEventElapsedTime(&t, evs_[0][0], evs_[nsub - 1][7]);
     last_stats.total_ms = t;

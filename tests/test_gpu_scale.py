@@ -155,3 +155,35 @@ def test_pairs_and_long_reads_against_oracle_and_cuts(world):
     assert np.array_equal(scr, scl[order]) and np.array_equal(slr, sll[order])
     o.close()
     dev.close()
+
+
+def test_many_near_identical_strains_general_fold(tmp_path):
+    """20 strains per species at 0.1 % steps: ranges of 10-40 rows per hit, so nearly every read takes the general form of
+    the per-read fold (hash table in pool scratch, pool growth on the way).  Cross-checked against the sort-based fold of the
+    two-kernel path on every read, against the plain FM-index walk, and against the C oracle on a subsample."""
+    import torch
+    from centrifuger_amd import indexbuild
+    k = 2
+    g = synth.make_genomes(8, 20, 60_000, seed=991, divergence_step=0.001)
+    prefix = str(tmp_path / "idx")
+    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    n = 150_000
+    rs = synth.make_reads(g, n, 150, seed=992, sub_rate=0.005, n_rate=0.0005)
+    idx, dev = _open(prefix, k, {"CFR_POOL_INIT": "1000"})
+    res, mat = dev.classify(rs.bases, rs.offsets)
+    ref = digest(*canon(res, mat, k))
+    res_b, mat_b = dev.classify(rs.bases, rs.offsets)            # the pool has grown by now: same answers
+    assert digest(*canon(res_b, mat_b, k)) == ref
+    dev.close()
+    for env in ({"CFR_FUSED_POST": "0"}, {"CFR_FTABX_WIDTH": "0", "CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0"}):
+        idx2, dev2 = _open(prefix, k, env)
+        r2, m2 = dev2.classify(rs.bases, rs.offsets)
+        assert digest(*canon(r2, m2, k)) == ref, env
+        dev2.close()
+    o = ora.OracleIndex(prefix, max_result=k)
+    m = 2500
+    ores = o.classify(rs.bases[:m * 150], rs.offsets[:m + 1], threads=16)
+    for i in range(m):
+        assert idx.format_tsv("r", res[i], mat) == o.format("r", ores[i]), i
+    o.close()
+    assert float((res["n_match"] > 0).mean()) > 0.99

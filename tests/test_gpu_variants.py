@@ -18,6 +18,7 @@ VARIANTS = {
     "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003", "CFR_TAPER_FLOOR": "0"},
     "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
     "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
+    "post_pool_growth": {"CFR_POOL_INIT": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "fast_load_profile": {"CFR_PROFILE": "fast-load"},
     "tapered_last_subbatch": {"CFR_SUBBATCH": "300", "CFR_TAPER_FLOOR": "5"},
     "unfused_tail": {"CFR_FUSED_TAIL": "0", "CFR_SUBBATCH": "61"},
