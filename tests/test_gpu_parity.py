@@ -206,3 +206,32 @@ def test_fresh_index_against_reference_binary_and_oracle(paired, k, tmp_path):
     st = d.last_stats()
     # (n_hits / n_rows are only counted by the pipelines that need those totals on the host: the one-launch post stage does not)
     assert st.n_chains == n * (4 if paired else 2)
+
+
+def test_old_format_index_without_end_marker_field(golden_dir, tmp_path):
+    """An index file that ends before the `hasEndMarker` byte (written by older reference versions, FMIndex.hpp:178-181)
+    classifies exactly like the full file."""
+    import shutil
+    full = open(os.path.join(golden_dir, "f6.1.cfr"), "rb").read()
+    for ext in (".2.cfr", ".3.cfr", ".4.cfr"):
+        if os.path.exists(os.path.join(golden_dir, "f6" + ext)):
+            shutil.copy(os.path.join(golden_dir, "f6" + ext), tmp_path / ("old" + ext))
+    (tmp_path / "old.1.cfr").write_bytes(full[:-1])
+    case = MAN["cases"]["f6.se_k1"] if "f6.se_k1" in MAN["cases"] else None
+    idx = capi.Index(str(tmp_path / "old"), capi.default_params(max_result=1))
+    d = capi.DeviceIndex(idx)
+    rs_ids, b, o = [], [], [0]
+    for rec in open(os.path.join(golden_dir, "se.fq"), "rb").read().split(b"\n@")[:400]:
+        lines = rec.split(b"\n")
+        rs_ids.append(lines[0].lstrip(b"@").split()[0].decode())
+        b.append(lines[1])
+        o.append(o[-1] + len(lines[1]))
+    bases = np.frombuffer(b"".join(b), dtype=np.uint8).copy()
+    offs = np.array(o, dtype=np.uint64)
+    res, mat = d.classify(bases, offs)
+    idx_full = capi.Index(os.path.join(golden_dir, "f6"), capi.default_params(max_result=1))
+    d_full = capi.DeviceIndex(idx_full)
+    res2, mat2 = d_full.classify(bases, offs)
+    assert res.tobytes() == res2.tobytes() and mat.tobytes() == mat2.tobytes() and int((res["n_match"] > 0).sum()) > 300
+    d.close()
+    d_full.close()

@@ -286,3 +286,29 @@ def test_cli_read_parser(tmp_path, gz):
     oi = subprocess.run([cli, "-x", "unused", "-i", str(tmp_path / "inter.fq")], env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     want = b"".join(a[0] + b"\t" + a[1] + b"\t" + b[1] + b"\tq:" + a[2] + b"\n" for a, b in zip(r1, r2))
     assert o2 == want and oi == want
+
+
+def test_index_written_before_the_end_marker_field(golden_dir, tmp_path, oracle_bin):
+    """Indexes written before `hasEndMarker` existed end one byte earlier (FMIndex.hpp:178-181 loads them with the flag
+    false).  The parser accepts such a file, and the oracle classifies with it exactly as with the full one."""
+    import shutil
+    import subprocess
+    full = open(os.path.join(golden_dir, "f6.1.cfr"), "rb").read()
+    assert full[-1] == 0                                  # the flag of a nucleotide index
+    for ext in (".2.cfr", ".3.cfr", ".4.cfr"):
+        if os.path.exists(os.path.join(golden_dir, "f6" + ext)):
+            shutil.copy(os.path.join(golden_dir, "f6" + ext), tmp_path / ("old" + ext))
+    (tmp_path / "old.1.cfr").write_bytes(full[:-1])
+    a, b = capi.Index(os.path.join(golden_dir, "f6")).info(), capi.Index(str(tmp_path / "old")).info()
+    for f in ("n", "block_size", "precompute_width", "sample_rate", "seq_cnt", "selected_cnt", "min_hit_len"):
+        assert getattr(a, f) == getattr(b, f)
+    reads = os.path.join(golden_dir, "se.fq")
+    out_full = subprocess.run([oracle_bin, "classify", "-x", os.path.join(golden_dir, "f6"), "-u", reads], check=True, stdout=subprocess.PIPE).stdout
+    out_old = subprocess.run([oracle_bin, "classify", "-x", str(tmp_path / "old"), "-u", reads], check=True, stdout=subprocess.PIPE).stdout
+    assert out_old == out_full and out_full.count(b"\n") > 100
+    # a file cut anywhere else is a format error, not a crash
+    for cut in (len(full) // 3, len(full) - 9):
+        (tmp_path / "old.1.cfr").write_bytes(full[:cut])
+        with pytest.raises(capi.CfrError) as e:
+            capi.Index(str(tmp_path / "old"))
+        assert e.value.status in (capi.CFR_ERR_FORMAT, capi.CFR_ERR_IO)
