@@ -217,7 +217,6 @@ def test_old_format_index_without_end_marker_field(golden_dir, tmp_path):
         if os.path.exists(os.path.join(golden_dir, "f6" + ext)):
             shutil.copy(os.path.join(golden_dir, "f6" + ext), tmp_path / ("old" + ext))
     (tmp_path / "old.1.cfr").write_bytes(full[:-1])
-    case = MAN["cases"]["f6.se_k1"] if "f6.se_k1" in MAN["cases"] else None
     idx = capi.Index(str(tmp_path / "old"), capi.default_params(max_result=1))
     d = capi.DeviceIndex(idx)
     rs_ids, b, o = [], [], [0]
