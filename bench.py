@@ -70,6 +70,31 @@ def build_index(args, cache, device=None):
     return prefix
 
 
+def bind_to_gpu_numa_node(torch, local_rank):
+    """One process per GPU: keep the process (and therefore the pinned result buffers it allocates and the copies into them)
+    on the NUMA node the GPU hangs off.  Best effort; CFR_BENCH_NO_NUMA=1 turns it off.  Returns the node or None."""
+    if os.environ.get("CFR_BENCH_NO_NUMA") == "1":
+        return None
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            log(f"rank on GPU {local_rank} ({bdf}) bound to NUMA node {node} ({len(cpus)} cpus)")
+            return node
+    except Exception as e:      # containers without sysfs, older torch: run unbound
+        log(f"NUMA binding skipped: {e}")
+    return None
+
+
 def make_reads_gpu(torch, cat_d, starts, n_reads, read_len, seed, device, sub_rate=0.01, n_rate=0.001):
     """Synthetic reads generated directly in HBM (uniform over genomes/positions/strands, 1 % subs, 0.1 % N)."""
     gen = torch.Generator(device=device)
@@ -237,6 +262,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if share_gpu else "nccl")
 
+    all_cpus = os.sched_getaffinity(0)
+    numa = bind_to_gpu_numa_node(torch, local_rank)      # host threads + pinned buffers next to this rank's GPU
     from centrifuger_amd import capi
     key = hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")).encode()).hexdigest()[:10]
     cache = os.path.join(args.cache, key)
@@ -311,6 +338,7 @@ def main():
     from centrifuger_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist=dist, device=None if share_gpu else device)   # the job is as slow as its slowest rank
     classified = int((results["n_match"] > 0).sum())
+    os.sched_setaffinity(0, all_cpus)                    # the CPU legs below (oracle counters, reference baseline) get every core back
 
     if rank != 0:
         if dist is not None:
@@ -328,7 +356,8 @@ def main():
                                (f"{args.reads} long reads (5-20 kbp, mean {total_bases/args.reads:.0f} bp) per step per GPU, -k {k}, inputs resident in HBM" if longmode else
                                 f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM"),
                    "index_bp": int(info.n), "reads_per_step_per_gpu": args.reads, "read_len": args.read_len,
-                   "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective"},
+                   "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
+                   "numa_node_of_rank0": numa},
         "classified_fraction": classified / args.reads,
         "stage_ms": {k: float(np.mean([getattr(s, k) for s in kstats])) for k in
                      ("pack_ms", "search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")},
@@ -416,6 +445,11 @@ def main():
             r2, m2 = dev.classify(b, rs.offsets, bb2, rs2.offsets)
         else:
             r2, m2 = dev.classify(b, rs.offsets)
+            # the same entry once more, timed: host (pageable) buffers in, host buffers out = the PCIe-inclusive rate (never `value`)
+            t0 = time.perf_counter()
+            dev.classify(b, rs.offsets)
+            out["pcie_inclusive"] = {"value": nb / (time.perf_counter() - t0), "unit": "reads/s",
+                                     "note": f"cfr_classify_batch on {nb} reads from pageable host memory to pageable host memory (H2D 150 B/read, D2H 64 B/read)"}
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
         out["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": ncpu, "kind": "reference",
                                "sample": f"first {nb} {'pairs' if paired else 'reads'} of the step batch, oracle/_ref/centrifuger -t {ncpu} -k {k}, "
