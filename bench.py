@@ -380,6 +380,8 @@ def main():
     ach = bytes_search * args.reads / (search_ms / 1e3) / 1e9
     traffic = requests = None
     try:   # HBM/fabric bytes from the PMC passes of the same kernel (tools/pmc_passes.sh -> profiles/pmc_latest.json), scaled per read
+        if args.mode != "se" or args.read_len != 150:
+            raise ValueError("the committed PMC profile is of the single-end 150 bp workload")
         pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
         pm = pmj["k_search_chains_v2"]
         traffic = (pm["fabric_read_bytes_per_read"] + pm["write_bytes_per_read"]) * args.reads
