@@ -47,7 +47,8 @@ MATCH_DTYPE = np.dtype([("id", "<u8"), ("taxid", "<u8"), ("kind", "<i4"), ("pad"
 
 EXPORTS = [
     "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
-    "cfr_device_count", "cfr_device_index_create", "cfr_device_index_destroy", "cfr_device_index_get_info",
+    "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
+    "cfr_device_index_destroy", "cfr_device_index_get_info",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
@@ -154,13 +155,33 @@ class Index:
             return results, matches[:nm.value]
 
 
+class DeviceOptions(C.Structure):
+    """cfr_device_options (include/cfr_hip.h)."""
+    _fields_ = [("profile", C.c_int32), ("ftabx_width", C.c_int32), ("text_mode", C.c_int32), ("run_block_layout", C.c_int32),
+                ("loc_memo_gb", C.c_double), ("sub_batch", C.c_uint64)]
+
+
+PROFILE_THROUGHPUT, PROFILE_FAST_LOAD = 0, 1
+
+
+def default_device_options(**kw) -> DeviceOptions:
+    o = DeviceOptions()
+    lib().cfr_device_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
 class DeviceIndex:
     """cfr_dev_index: the flat index image in one GPU's HBM + the batch entry points."""
 
-    def __init__(self, index: Index, device: int = 0):
+    def __init__(self, index: Index, device: int = 0, options: DeviceOptions | None = None):
         self.index = index
         self._d = C.c_void_p()
-        _check(lib().cfr_device_index_create(index._h, C.c_int(device), C.byref(self._d)))
+        if options is None:
+            _check(lib().cfr_device_index_create(index._h, C.c_int(device), C.byref(self._d)))
+        else:
+            _check(lib().cfr_device_index_create_ex(index._h, C.c_int(device), C.byref(options), C.byref(self._d)))
 
     def info(self) -> IndexInfo:
         info = IndexInfo()

@@ -76,13 +76,30 @@ cfr_status cfr_device_count(int *count) {
   *count = c;
   return CFR_OK;
 }
-cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out) {
+void cfr_device_options_default(cfr_device_options *o) {
+  if (!o) return;
+  o->profile = CFR_PROFILE_THROUGHPUT;
+  o->ftabx_width = -1;
+  o->text_mode = -1;
+  o->run_block_layout = 0;
+  o->loc_memo_gb = -1.0;
+  o->sub_batch = 0;
+}
+cfr_status cfr_device_index_create_ex(const cfr_index *idx, int device, const cfr_device_options *options, cfr_dev_index **out) {
   if (!idx || !out) return bad_arg("cfr_device_index_create: null argument");
+  cfr_device_options o;
+  cfr_device_options_default(&o);
+  if (options) o = *options;
+  if (o.profile != CFR_PROFILE_THROUGHPUT && o.profile != CFR_PROFILE_FAST_LOAD) return bad_arg("cfr_device_index_create_ex: unknown profile");
+  if (o.ftabx_width < -1 || o.ftabx_width > 16) return bad_arg("cfr_device_index_create_ex: ftabx_width out of range");
   return guarded([&]() -> cfr_status {
-    cfr::DeviceIndex *d = new cfr::DeviceIndex(*idx->h, device);
+    cfr::DeviceIndex *d = new cfr::DeviceIndex(*idx->h, device, o);
     *out = new cfr_dev_index{d, idx, default_tail_threads()};
     return CFR_OK;
   });
+}
+cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out) {
+  return cfr_device_index_create_ex(idx, device, nullptr, out);
 }
 void cfr_device_index_destroy(cfr_dev_index *d) { if (d) { delete d->d; delete d; } }
 cfr_status cfr_device_index_get_info(const cfr_dev_index *d, cfr_index_info *info) {

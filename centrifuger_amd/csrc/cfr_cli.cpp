@@ -5,7 +5,7 @@
 // --un/--cl read dumps, same stderr summary lines.  What the reference does with
 // pthread_create(ClassifyReads_Thread) per batch (CentrifugerClass.cpp:681-688) is one
 // cfr_classify_batch call per batch here; batches round-robin over the GPUs given by --gpu, output stays
-// in input order.  Additive options: --gpu LIST|all, --gpu-batch N.
+// in input order.  Additive options: --gpu LIST|all, --gpu-batch N, --gpu-throughput.
 // Options of the reference that are outside this build (barcode/UMI/read-format/sample-sheet/
 // merge-readpair/expand-taxid) are rejected with a message instead of being silently ignored.
 #include <getopt.h>
@@ -49,11 +49,12 @@ const char *kUsage =
     "\t--hitk-factor INT: resolve at most <int>*k entries for each hit [40; use 0 for no restriction]\n"
     "\t--consider-secondary STR: in the format INT,FLOAT consider the secondary hit if its hitlen>=INT,score>=FLOAT*best_score [2000,0.995]\n"
     "\t--gpu LIST: comma separated MI355X ordinals, or 'all' [0]\n"
-    "\t--gpu-batch INT: reads per device batch [1048576]\n"
+    "\t--gpu-batch INT: reads per device batch [262144]\n"
+    "\t--gpu-throughput: build every derived table on the device (longer load, faster classification) [short load]\n"
     "\t-h: print this usage message\n"
     "\t-v: print the version information and quit\n";
 
-enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_UNSUPPORTED };
+enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_GPU_THROUGHPUT, OPT_UNSUPPORTED };
 
 void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp:369-381)
   char buffer[1024];
@@ -196,6 +197,7 @@ struct Options {
   std::vector<int> gpus{0};
   bool all_gpus = false;
   size_t gpu_batch = 1u << 18;
+  bool throughput_profile = false;
 };
 
 // gz read dumps (ResultWriter::SetOutputReads, ResultWriter.hpp:126-176)
@@ -244,7 +246,7 @@ int main(int argc, char *argv[]) {
       {"un", required_argument, 0, OPT_UN}, {"cl", required_argument, 0, OPT_CL}, {"no-dust", no_argument, 0, OPT_NO_DUST},
       {"min-hitlen", required_argument, 0, OPT_MIN_HITLEN}, {"hitk-factor", required_argument, 0, OPT_HITK},
       {"consider-secondary", required_argument, 0, OPT_SECONDARY}, {"gpu", required_argument, 0, OPT_GPU},
-      {"gpu-batch", required_argument, 0, OPT_GPU_BATCH},
+      {"gpu-batch", required_argument, 0, OPT_GPU_BATCH}, {"gpu-throughput", no_argument, 0, OPT_GPU_THROUGHPUT},
       {"sample-sheet", required_argument, 0, OPT_UNSUPPORTED}, {"merge-readpair", no_argument, 0, OPT_UNSUPPORTED},
       {"expand-taxid", no_argument, 0, OPT_UNSUPPORTED}, {"read-format", required_argument, 0, OPT_UNSUPPORTED},
       {"barcode", required_argument, 0, OPT_UNSUPPORTED}, {"UMI", required_argument, 0, OPT_UNSUPPORTED},
@@ -285,6 +287,7 @@ int main(int argc, char *argv[]) {
         }
         break;
       case OPT_GPU_BATCH: opt.gpu_batch = strtoull(optarg, nullptr, 10); break;
+      case OPT_GPU_THROUGHPUT: opt.throughput_profile = true; break;
       case OPT_UNSUPPORTED:
         print_log("ERROR: option --%s belongs to a part of Centrifuger outside the MI355X classification path and is not available in this build.",
                   long_options[option_index].name);
@@ -455,10 +458,12 @@ int main(int argc, char *argv[]) {
   }
   std::vector<cfr_dev_index *> devs;
   t0 = tick();
-  setenv("CFR_PROFILE", "fast-load", 0);     // this program is bound by parsing; prefer a short load (export CFR_PROFILE=throughput to build every table)
+  cfr_device_options dopt;
+  cfr_device_options_default(&dopt);
+  dopt.profile = opt.throughput_profile ? CFR_PROFILE_THROUGHPUT : CFR_PROFILE_FAST_LOAD;   // this program is bound by parsing: prefer a short load
   for (int g : opt.gpus) {
     cfr_dev_index *d = nullptr;
-    st = cfr_device_index_create(idx, g, &d);
+    st = cfr_device_index_create_ex(idx, g, &dopt, &d);
     if (st != CFR_OK) die_status("creating the device index (this build has no CPU fallback)", st);
     devs.push_back(d);
   }

@@ -57,7 +57,7 @@ void *DeviceIndex::scratch(size_t slot, size_t bytes) {
   return s.p;
 }
 
-DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(device) {
+DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_options &opt) : host_(&h), device_(device) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"no HIP device available (libcfr_hip has no CPU fallback)", -1};
   if (device < 0 || device >= count) throw HipError{"device ordinal out of range", -1};
@@ -71,6 +71,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
   else if (const char *e2 = getenv("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
+  if (opt.sub_batch) sub_batch_ = (size_t)opt.sub_batch;
   if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -93,8 +94,9 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   lap("context, streams, events");
   // CFR_PROFILE=fast-load: skip the large derived tables (a command-line run is bound by FASTQ parsing, not by the device;
   // what it feels is the load time).  Default: throughput (all tables).  The specific switches below override either.
-  const bool fast_load = getenv("CFR_PROFILE") && std::string(getenv("CFR_PROFILE")) == "fast-load";
-  bool layout_rb = false;
+  bool fast_load = opt.profile == CFR_PROFILE_FAST_LOAD;
+  if (const char *e = getenv("CFR_PROFILE")) fast_load = std::string(e) == "fast-load";
+  bool layout_rb = opt.run_block_layout != 0;
   if (const char *e = getenv("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
   memset(&view_.rb, 0, sizeof(view_.rb));
   uint64_t *d_occ = nullptr;
@@ -254,6 +256,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
       while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
     if (fast_load) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
+    if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
@@ -270,8 +273,9 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
   view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
-    bool want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb && !fast_load;
-    if (const char *e = getenv("CFR_TEXT_MODE")) want = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb && atoi(e) != 0;
+    const bool possible = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb;
+    bool want = possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
+    if (const char *e = getenv("CFR_TEXT_MODE")) want = possible && atoi(e) != 0;
     if (want) try {
       uint2 *la = nullptr, *lb = nullptr;
       HIP_CHECK(hipMalloc((void **)&la, h.n * sizeof(uint2)));
@@ -306,7 +310,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device) : host_(&h), device_(de
   view_.loc_memo = nullptr;
   view_.memo_shift = 0;
   {
-    double budget_gb = fast_load ? 0.0 : 16.0;
+    double budget_gb = opt.loc_memo_gb >= 0 ? opt.loc_memo_gb : (fast_load ? 0.0 : 16.0);
     if (const char *e = getenv("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;
     for (uint64_t x : h.selected_vals) max_val = std::max(max_val, x);

@@ -89,7 +89,7 @@ void host_free_pinned(void *p);
 
 class DeviceIndex {
  public:
-  DeviceIndex(const HostIndex &h, int device);
+  DeviceIndex(const HostIndex &h, int device, const cfr_device_options &opt);
   ~DeviceIndex();
 
   const HostIndex &host() const { return *host_; }

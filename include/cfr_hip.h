@@ -117,6 +117,22 @@ cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info);
 
 cfr_status cfr_device_count(int *count);
 cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out);
+
+/* What the device image is built with.  Nothing here changes a result; it trades load time and HBM for throughput.
+ * cfr_device_index_create == cfr_device_index_create_ex with the defaults.  (The CFR_* environment variables listed in
+ * DESIGN.md section 5 override these fields when set: they exist for A/B runs and for the variant tests.) */
+typedef enum { CFR_PROFILE_THROUGHPUT = 0, CFR_PROFILE_FAST_LOAD = 1 } cfr_profile;
+typedef struct {
+  int32_t profile;        /* cfr_profile.  FAST_LOAD: K-mer table of at most 4^13 entries, no text-mode tables, no locate memo
+                             (load 0.3 s instead of 1.2 s per Gbp; what a parse-bound command line wants) */
+  int32_t ftabx_width;    /* K of the derived K-mer table; -1 = automatic (log4(n)+2, at most 16, a quarter of the free HBM), 0 = none */
+  int32_t text_mode;      /* derived SA / ISA / 2-bit text (n < 2^32): -1 = by profile, 0 = off, 1 = on */
+  int32_t run_block_layout; /* 1 = keep the run-block components compressed in HBM instead of the flat occurrence image */
+  double loc_memo_gb;     /* byte budget of the locate memo in GB; negative = by profile (16 / none), 0 = none */
+  uint64_t sub_batch;     /* reads per sub-batch of one batch call; 0 = default */
+} cfr_device_options;
+void cfr_device_options_default(cfr_device_options *o);
+cfr_status cfr_device_index_create_ex(const cfr_index *idx, int device, const cfr_device_options *options, cfr_dev_index **out);
 void cfr_device_index_destroy(cfr_dev_index *d);
 cfr_status cfr_device_index_get_info(const cfr_dev_index *d, cfr_index_info *info);
 

@@ -49,8 +49,7 @@ def test_cli_several_device_workers_keep_input_order(golden_dir):
     base = [CLI, "-x", os.path.join(golden_dir, "f6"), "-1", os.path.join(golden_dir, "pe_1.fq"), "-2", os.path.join(golden_dir, "pe_2.fq"), "-k", "5"]
     out = subprocess.run(base + ["--gpu", "0,0,0", "--gpu-batch", "25", "-t", "4"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert out == want
-    out = subprocess.run(base + ["--gpu", "all"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                         env=dict(os.environ, CFR_PROFILE="throughput")).stdout
+    out = subprocess.run(base + ["--gpu", "all", "--gpu-throughput"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert out == want
 
 

@@ -118,6 +118,25 @@ def test_permutation_cut_and_determinism_single_end(world):
     o.close()
 
 
+def test_device_options_entry_gives_the_same_answers(world):
+    """cfr_device_index_create_ex: profiles and table switches passed explicitly (no environment)."""
+    k = 3
+    rs = world["reads"]
+    n = 200_000
+    b, o = rs.bases[:n * READ_LEN], rs.offsets[:n + 1]
+    idx = capi.Index(world["prefix"], capi.default_params(max_result=k))
+    dev = capi.DeviceIndex(idx)
+    ref = digest(*canon(*dev.classify(b, o), k))
+    full_bytes = dev.info().device_bytes
+    dev.close()
+    for kw in (dict(profile=capi.PROFILE_FAST_LOAD), dict(ftabx_width=0, text_mode=0, loc_memo_gb=0.0), dict(ftabx_width=12, sub_batch=7777),
+               dict(run_block_layout=1)):
+        d2 = capi.DeviceIndex(idx, 0, capi.default_device_options(**kw))
+        assert digest(*canon(*d2.classify(b, o), k)) == ref, kw
+        assert d2.info().device_bytes < full_bytes
+        d2.close()
+
+
 def test_pairs_and_long_reads_against_oracle_and_cuts(world):
     k = 5
     idx, dev = _open(world["prefix"], k)

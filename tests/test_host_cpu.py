@@ -28,6 +28,9 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert capi.HIT_DTYPE.itemsize == 32 and capi.RESULT_DTYPE.itemsize == 40 and capi.MATCH_DTYPE.itemsize == 24
     assert C.sizeof(capi.Params) == 32
+    assert C.sizeof(capi.DeviceOptions) == 32
+    o = capi.default_device_options()
+    assert (o.profile, o.ftabx_width, o.text_mode, o.run_block_layout, o.sub_batch) == (capi.PROFILE_THROUGHPUT, -1, -1, 0, 0) and o.loc_memo_gb < 0
 
 
 @pytest.mark.parametrize("iname", ["f6", "f6_b1", "f6_b8", "f6_off3", "f10"])
@@ -59,6 +62,14 @@ def test_open_errors_are_statuses_not_exits(tmp_path):
     with pytest.raises(capi.CfrError) as e:
         capi.Index(str(prot))
     assert e.value.status == capi.CFR_ERR_FORMAT
+
+
+def test_device_options_are_validated_before_any_device_work(golden_dir):
+    idx = capi.Index(os.path.join(golden_dir, "f6"))
+    for bad in (dict(profile=7), dict(ftabx_width=17), dict(ftabx_width=-2)):
+        with pytest.raises(capi.CfrError) as e:
+            capi.DeviceIndex(idx, 0, capi.default_device_options(**bad))
+        assert e.value.status == capi.CFR_ERR_ARG
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(golden_dir):
