@@ -388,9 +388,27 @@ def main():
         requests = pm["TCC_EA0_RDREQ"] / pmj["reads_in_profiled_launch"] * args.reads
     except Exception:
         pass
+    # what a plain device copy sustains on this box ("also report against a measured device copy bandwidth")
+    copy_gbs = None
+    try:
+        xa = torch.empty(1 << 31, dtype=torch.uint8, device=device)
+        xb = torch.empty_like(xa)
+        xb.copy_(xa)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            xb.copy_(xa)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * xa.numel() / (e0.elapsed_time(e1) / 1e3) / 1e9      # read + write
+        del xa, xb
+    except Exception:
+        pass
     out["roofline"] = {
         "bound": "hbm", "kernel": "k_search_chains_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        "measured_copy_GBs": copy_gbs,       # torch device-to-device copy of 2 GiB, read + write bytes per second
         "algorithmic_bytes_per_read": bytes_search, "kernel_ms": search_ms,
         "per": "one step = the launches of the step's sub-batches (achieved, traffic and kernel_ms are all summed over them)",
         # the same kernel priced on what it really moves (PMC), and against the measured random-gather ceiling of the chip
@@ -452,6 +470,19 @@ def main():
             dev.classify(b, rs.offsets)
             out["pcie_inclusive"] = {"value": nb / (time.perf_counter() - t0), "unit": "reads/s",
                                      "note": f"cfr_classify_batch on {nb} reads from pageable host memory to pageable host memory (H2D 150 B/read, D2H 64 B/read)"}
+            # and the whole step batch with every host buffer pinned (cfr_host_alloc): the bases of sub-batch k+1 go up while
+            # sub-batch k computes, so the call is bound by the H2D copy (150 B/read)
+            pb = capi.PinnedArray(total_bases, np.uint8)
+            po = capi.PinnedArray(args.reads + 1, np.uint64)
+            pb.array[:] = reads_d.reshape(-1).cpu().numpy()
+            po.array[:] = offs_h
+            dev.classify(pb.array, po.array, results=results, matches=matches)
+            t0 = time.perf_counter()
+            dev.classify(pb.array, po.array, results=results, matches=matches)
+            out["pcie_inclusive"]["pinned_value"] = args.reads / (time.perf_counter() - t0)
+            out["pcie_inclusive"]["pinned_note"] = f"{args.reads} reads, bases / offsets / results / matches all in cfr_host_alloc memory"
+            pb.free()
+            po.free()
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
         out["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": ncpu, "kind": "reference",
                                "sample": f"first {nb} {'pairs' if paired else 'reads'} of the step batch, oracle/_ref/centrifuger -t {ncpu} -k {k}, "

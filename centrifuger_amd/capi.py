@@ -241,9 +241,16 @@ class DeviceIndex:
             _check(st)
             return hits[:int(hit_begin[n])], hit_begin
 
-    def classify(self, bases1, offsets1, bases2=None, offsets2=None):
+    def classify(self, bases1, offsets1, bases2=None, offsets2=None, results=None, matches=None):
+        """Host buffers in, host buffers out (cfr_classify_batch).  results / matches: caller-provided arrays (e.g. PinnedArray
+        views; matches must hold max_result slots per read) instead of fresh numpy arrays."""
         bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
         n = len(offsets1) - 1
+        if results is not None and matches is not None:
+            nm = C.c_size_t(0)
+            _check(lib().cfr_classify_batch(self._d, _p(bases1), _p(offsets1), _p(bases2), _p(offsets2), C.c_size_t(n),
+                                            _p(results), _p(matches), C.c_size_t(len(matches)), C.byref(nm)))
+            return results, matches[:nm.value]
         results = np.zeros(n, dtype=RESULT_DTYPE)
         cap = max(16, max(1, self.index.params.max_result) * n)
         while True:

@@ -68,6 +68,8 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
   HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
   for (auto &e : tail_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
   if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
   if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
   else if (const char *e2 = getenv("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
@@ -340,6 +342,8 @@ DeviceIndex::~DeviceIndex() {
   for (auto &set : evs_) for (auto &e : set) if (e) (void)hipEventDestroy(e);
   for (auto &e : tail_done_) if (e) (void)hipEventDestroy(e);
   for (auto &e : copy_done_) if (e) (void)hipEventDestroy(e);
+  for (auto &e : h2d_done_) if (e) (void)hipEventDestroy(e);
+  if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
   if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
   if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -590,14 +594,14 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
 }
 
 // 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
-void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2) {
+void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now) {
   // 4 zero blocks ("not a symbol") in front of and behind the packed form: the search kernel fetches block pairs
   auto pack_one = [&](size_t slot, const uint8_t *d_b, uint64_t total, uint64_t &nblk) -> uint64_t * {
     nblk = (total + 15) / 16;
     uint64_t *base = (uint64_t *)scratch(slot, (nblk + 8) * 8);
     HIP_CHECK(hipMemsetAsync(base, 0, 4 * 8, stream_));
     HIP_CHECK(hipMemsetAsync(base + 4 + nblk, 0, 4 * 8, stream_));
-    if (nblk) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(d_b, total, nblk, base + 4);
+    if (nblk && pack_now) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(d_b, total, nblk, base + 4);
     return base + 4;
   };
   packed1_ = pack_one(S_PACK1, d_b1, total1, nblk1_);
@@ -683,7 +687,7 @@ std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool pe
 
 void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
-                                  size_t *match_extent) {
+                                  size_t *match_extent, const HostSrc *src) {
   HIP_CHECK(hipSetDevice(device_));
   last_stats = cfr_batch_stats{};
   if (match_extent) *match_extent = 0;
@@ -691,13 +695,41 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
-  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/src == nullptr);
   size_t sb = 0;
   const auto pieces = cut_pieces(n, stride > 0, sb);
   const size_t nsub = pieces.size();
   const bool paired = d_b2 != nullptr;
   const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;     // k_tail answers rows from the memo itself
   const bool one_launch = fused && stride > 0 && fused_post_;                   // k_adjust_tail: no host round trip in a piece
+  // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
+  std::vector<uint8_t> have_piece(nsub, src ? 0 : 1);
+  auto bring_piece = [&](size_t k) {
+    if (!src || have_piece[k]) return;
+    const size_t lo = pieces[k].first, hi = lo + pieces[k].second;
+    auto one = [&](const uint8_t *hb, const uint64_t *ho, const uint8_t *db) {
+      const uint64_t a = ho[lo], b = ho[hi];
+      if (b > a) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
+    };
+    one(src->b1, src->o1, d_b1);
+    if (paired) one(src->b2, src->o2, d_b2);
+    HIP_CHECK(hipEventRecord(h2d_done_[k], h2d_stream_));
+    have_piece[k] = 1;
+  };
+  auto pack_piece = [&](size_t k) {            // on the main stream, behind the copy of the piece
+    if (!src) return;
+    const size_t lo = pieces[k].first, hi = lo + pieces[k].second;
+    HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
+    auto one = [&](const uint64_t *ho, const uint8_t *db, uint64_t total, uint64_t *packed) {
+      const uint64_t b0 = ho[lo] >> 4, b1x = (ho[hi] + 15) >> 4;          // the blocks the piece touches (a block shared with the
+      if (b1x > b0) k_pack_reads<<<grid_for(b1x - b0), kBlock, 0, stream_>>>(db + (b0 << 4), total - (b0 << 4), b1x - b0, packed + b0);   // next piece is packed again there)
+    };
+    one(src->o1, d_b1, total1, packed1_);
+    if (paired) one(src->o2, d_b2, total2, packed2_);
+    HIP_CHECK(hipGetLastError());
+  };
+  if (src && !one_launch) throw HipError{"streamed host inputs need the one-launch post stage", -4};
+  bring_piece(0);
 
   // results / matches of piece k leave through the buffer pair of its parity while piece k+1 computes
   auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag) {
@@ -732,6 +764,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const size_t lo = pieces[k].first, cnt = pieces[k].second;
         ovf[k] = 0;
         ev_ = evs_[k];
+        if (attempt == 0) { bring_piece(k); pack_piece(k); }
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
         unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 16);    // pool cursor, overflow flag
@@ -746,6 +779,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         HIP_CHECK(hipGetLastError());
         copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
+        if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
       HIP_CHECK(hipStreamSynchronize(stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
@@ -795,6 +829,24 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
 void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,
                                 cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent) {
   HIP_CHECK(hipSetDevice(device_));
+  static const bool stream_inputs = !(getenv("CFR_STREAM_INPUTS") && atoi(getenv("CFR_STREAM_INPUTS")) == 0);
+  if (n && stream_inputs && !search_v1_ && view_.max_result > 0 && one_launch_ready()) {
+    // streamed form: only the offsets go up front; the bases of sub-batch k+1 are copied (h2d stream) while sub-batch k computes
+    const HostSrc src{b1, o1, b2, o2};
+    const uint64_t t1 = o1[n], t2 = b2 ? o2[n] : 0;
+    uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, t1 + 16);
+    uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
+    HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+    uint8_t *d_b2 = nullptr;
+    uint64_t *d_o2 = nullptr;
+    if (b2) {
+      d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 16);
+      d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
+      HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+    }
+    classify_device(d_b1, d_o1, d_b2, d_o2, n, t1, t2, results, matches, match_cap, match_extent, &src);
+    return;
+  }
   Staged st = stage_inputs(b1, o1, b2, o2, n);
   classify_device(st.b1, st.o1, st.b2, st.o2, n, st.t1, st.t2, results, matches, match_cap, match_extent);
 }

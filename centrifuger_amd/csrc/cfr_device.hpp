@@ -87,6 +87,9 @@ struct CapacityError { std::string msg; };
 void *host_alloc_pinned(size_t bytes);
 void host_free_pinned(void *p);
 
+// host buffers of a batch whose bases are streamed to the device sub-batch by sub-batch (DeviceIndex::classify_host)
+struct HostSrc { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; };
+
 class DeviceIndex {
  public:
   DeviceIndex(const HostIndex &h, int device, const cfr_device_options &opt);
@@ -118,7 +121,7 @@ class DeviceIndex {
   // (fast when that memory came from cfr_host_alloc).  matches: stride entries per read.
   void classify_device(const uint8_t *d_bases1, const uint64_t *d_offs1, const uint8_t *d_bases2, const uint64_t *d_offs2,
                        size_t n, uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
-                       size_t *match_extent);
+                       size_t *match_extent, const struct HostSrc *src = nullptr);
   void classify_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2, size_t n,
                      cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent);
 
@@ -147,7 +150,8 @@ class DeviceIndex {
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
-  void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2);
+  void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true);
+  bool one_launch_ready() const { return fused_tail_ && fused_post_ && view_.loc_memo && view_.memo_shift == 0; }
 
   const HostIndex *host_;
   int device_;
@@ -160,8 +164,8 @@ class DeviceIndex {
   static constexpr size_t kMaxSub = 16;
   hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 around the search, 8 and 3-7 around the stages behind it
   hipEvent_t *ev_ = nullptr;
-  hipStream_t copy_stream_ = nullptr;
-  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {};
+  hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr;
+  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {};
   size_t sub_batch_ = 1250000, taper_floor_ = 262144;
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;

@@ -19,6 +19,7 @@ VARIANTS = {
     "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
     "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "post_pool_growth": {"CFR_POOL_INIT": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
+    "host_inputs_staged_up_front": {"CFR_STREAM_INPUTS": "0"},
     "fast_load_profile": {"CFR_PROFILE": "fast-load"},
     "tapered_last_subbatch": {"CFR_SUBBATCH": "300", "CFR_TAPER_FLOOR": "5"},
     "unfused_tail": {"CFR_FUSED_TAIL": "0", "CFR_SUBBATCH": "61"},
