@@ -197,7 +197,9 @@ cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n
   if (n && (!bases || !offsets)) return bad_arg("cfr_dust_mask_batch: null argument");
   if (threads < 1) threads = 1;
   auto work = [&](int tid) {
-    for (size_t i = (size_t)tid; i < n; i += (size_t)threads) cfr::dust_mask(bases + offsets[i], offsets[i + 1] - offsets[i]);
+    // a contiguous slice per thread (reads are independent; the reference strides them, the result is the same)
+    const size_t lo = n * (size_t)tid / (size_t)threads, hi = n * (size_t)(tid + 1) / (size_t)threads;
+    for (size_t i = lo; i < hi; ++i) cfr::dust_mask(bases + offsets[i], offsets[i + 1] - offsets[i]);
   };
   if (threads == 1) work(0);
   else {

@@ -23,6 +23,7 @@
 #include <string>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -185,6 +186,57 @@ struct Batch {
     ids.clear(); id_off.clear(); qual1.clear(); qual2.clear(); q1_off.clear(); q2_off.clear(); has_qual.clear(); has_qual2.clear();
     bases1.clear(); bases2.clear(); offs1.clear(); offs2.clear(); tsv.clear();
   }
+};
+
+// Persistent workers for the dust and the format stage: a 256 k-read batch is 6 ms of work on 64 threads, less than
+// what starting 64 threads costs, so the threads are started once.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) : n_(n < 1 ? 1 : n) {
+    for (int t = 1; t < n_; ++t) th_.emplace_back([this, t]() { loop(t); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; ++gen_; }
+    cv_.notify_all();
+    for (auto &x : th_) x.join();
+  }
+  int size() const { return n_; }
+  // fn(t) for t in [0, parts): parts <= size(); the caller runs part 0 itself and returns when all are done
+  void run(int parts, const std::function<void(int)> &fn) {
+    if (parts <= 1) { fn(0); return; }
+    { std::lock_guard<std::mutex> lk(mu_); fn_ = &fn; parts_ = parts; pending_ = parts - 1; ++gen_; }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&]() { return pending_ == 0; });
+  }
+
+ private:
+  void loop(int t) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(int)> *fn;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&]() { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+        if (t >= parts_) continue;
+        fn = fn_;
+      }
+      (*fn)(t);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  int n_;
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int parts_ = 0, pending_ = 0;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
 };
 
 struct Options {
@@ -415,6 +467,7 @@ int main(int argc, char *argv[]) {
   });
 
   // dust stage (CentrifugerClass.cpp:276-316): needs no index either
+  WorkerPool dust_pool(opt.threads), format_pool(opt.threads);
   std::thread duster([&]() {
     for (;;) {
       std::shared_ptr<Batch> b;
@@ -426,9 +479,13 @@ int main(int argc, char *argv[]) {
         pending.pop_front();
       }
       const auto ts = tick();
-      if (opt.dust) {
-        cfr_dust_mask_batch(b->bases1.data(), b->offs1.data(), b->n, opt.threads);
-        if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data(), b->n, opt.threads);
+      if (opt.dust) {      // slices of the batch on the stage's own workers (offsets are absolute, so a slice is just an offset window)
+        const int parts = (int)std::min<size_t>((size_t)dust_pool.size(), std::max<size_t>(1, b->n / 2048));
+        dust_pool.run(parts, [&](int t) {
+          const size_t lo = b->n * (size_t)t / (size_t)parts, hi = b->n * (size_t)(t + 1) / (size_t)parts;
+          cfr_dust_mask_batch(b->bases1.data(), b->offs1.data() + lo, hi - lo, 1);
+          if (b->paired) cfr_dust_mask_batch(b->bases2.data(), b->offs2.data() + lo, hi - lo, 1);
+        });
       }
       clk.add(T_DUST, ts);
       std::lock_guard<std::mutex> lk(mu);
@@ -517,11 +574,12 @@ int main(int argc, char *argv[]) {
         classified_q.pop_front();
       }
       const auto ts = tick();
-      const int nt = (int)std::min<size_t>((size_t)opt.threads, std::max<size_t>(1, b->n / 4096));
+      const int nt = (int)std::min<size_t>((size_t)format_pool.size(), std::max<size_t>(1, b->n / 4096));
       std::vector<std::string> parts((size_t)nt);
-      auto fmt = [&](int t) {
+      format_pool.run(nt, [&](int t) {
         const size_t lo = b->n * (size_t)t / (size_t)nt, hi = b->n * (size_t)(t + 1) / (size_t)nt;
         std::string &out = parts[(size_t)t];
+        out.reserve((hi - lo) * 96);
         char buf[8192];
         for (size_t i = lo; i < hi; ++i) {
           size_t w = cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), buf, sizeof(buf));
@@ -532,13 +590,7 @@ int main(int argc, char *argv[]) {
             out.append(big.data(), w);
           }
         }
-      };
-      if (nt == 1) fmt(0);
-      else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(fmt, t);
-        for (auto &x : th) x.join();
-      }
+      });
       for (auto &p : parts) b->tsv += p;
       clk.add(T_FORMAT, ts);
       std::lock_guard<std::mutex> lk(mu);

@@ -23,11 +23,17 @@ inline int code_of(uint8_t ch) {
 
 // State of one SDUST scan (Morgulis et al. 2006).  Triplet ring buffer of capacity 128 like
 // Dustmasker_Queue(64) (Dustmasker.hpp:46-55).
+// One Scanner per thread, reused from read to read (reset() instead of construction: no allocation in the steady state,
+// 1 KB of counters to clear instead of 4 KB).
 class Scanner {
  public:
-  explicit Scanner(std::vector<Interval> &result) : result_(result) {
+  explicit Scanner(std::vector<Interval> &result) : result_(result) { reset(); }
+  void reset() {
     memset(cw_, 0, sizeof(cw_));
     memset(cv_, 0, sizeof(cv_));
+    perfect_.clear();
+    head_ = tail_ = 0;
+    rw_ = rv_ = lv_ = 0;
   }
 
   void run(const uint8_t *s, size_t n) {
@@ -48,8 +54,8 @@ class Scanner {
  private:
   int size() const { return (tail_ - head_) & 127; }
   int at(int i) const { return ring_[(head_ + i) & 127]; }
-  static void add(int t, int *cnt, int &r) { r += cnt[t]; ++cnt[t]; }
-  static void remove(int t, int *cnt, int &r) { --cnt[t]; r -= cnt[t]; }
+  static void add(int t, uint8_t *cnt, int &r) { r += cnt[t]; ++cnt[t]; }       // counts stay below the window (64)
+  static void remove(int t, uint8_t *cnt, int &r) { --cnt[t]; r -= cnt[t]; }
 
   // Dustmasker::ShiftWindow (:106-138)
   void shift(int t) {
@@ -116,9 +122,9 @@ class Scanner {
 
   std::vector<Interval> &result_;
   std::vector<Interval> perfect_;
-  int ring_[128];
+  int16_t ring_[128];
   int head_ = 0, tail_ = 0;
-  int cw_[512], cv_[512];
+  uint8_t cw_[512], cv_[512];
   int rw_ = 0, rv_ = 0, lv_ = 0;
 };
 
@@ -126,7 +132,9 @@ class Scanner {
 
 void dust_mask(uint8_t *s, size_t n) {
   if (n < 3) return;
-  std::vector<Interval> all, part;
+  thread_local std::vector<Interval> all, part;
+  thread_local Scanner sc(part);
+  all.clear();
   size_t i = 0;
   while (i < n && code_of(s[i]) == kOther) ++i;
   while (i < n) {
@@ -141,7 +149,7 @@ void dust_mask(uint8_t *s, size_t n) {
     }
     if (last_valid > i) {
       part.clear();
-      Scanner sc(part);
+      sc.reset();
       sc.run(s + i, last_valid - i + 1);
       for (const Interval &iv : part) all.push_back(Interval{iv.start + i, iv.end + i, iv.score});
     }
