@@ -64,3 +64,30 @@ def test_cli_read_dumps_match_reference(golden_dir, tmp_path):
                        check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     for name in ("un.fq.gz", "cl.fq.gz", "pun_1.fq.gz", "pun_2.fq.gz", "pcl_1.fq.gz", "pcl_2.fq.gz"):
         assert gzip.open(tmp_path / f"gpu_{name}").read() == gzip.open(tmp_path / f"ref_{name}").read(), name
+
+
+OPTION_SETS = {
+    "minhit10_k3": ["--min-hitlen", "10", "-k", "3"],            # hits shorter than the score offset: scores of 0 enter the fold
+    "minhit12": ["--min-hitlen", "12"],
+    "secondary_1_0.5_k2": ["--consider-secondary", "1,0.5", "-k", "2"],
+    "secondary_30_0.9_k4": ["--consider-secondary", "30,0.9", "-k", "4"],
+    "hitk1": ["--hitk-factor", "1"],
+    "hitk_negative_k2": ["--hitk-factor", "-1", "-k", "2"],
+    "k64": ["-k", "64"],
+}
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
+@pytest.mark.parametrize("name", sorted(OPTION_SETS))
+@pytest.mark.parametrize("profile", ["fast-load", "throughput"])
+def test_cli_option_corners_against_the_live_reference(name, profile, golden_dir):
+    """Option values no committed fixture covers, checked against the reference binary run on the spot (both profiles of the
+    command line: the multi-kernel path without derived tables, and the one-launch path with all of them)."""
+    opts = OPTION_SETS[name]
+    for reads in (["-u", os.path.join(golden_dir, "se.fq")], ["-1", os.path.join(golden_dir, "pe_1.fq"), "-2", os.path.join(golden_dir, "pe_2.fq")],
+                  ["-u", os.path.join(golden_dir, "edge.fa")]):
+        want = subprocess.run([os.path.join(REF_DIR, "centrifuger"), "-x", os.path.join(golden_dir, "f6"), "-t", "2"] + reads + opts,
+                              check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        got = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-t", "2"] + reads + opts + (["--gpu-throughput"] if profile == "throughput" else []),
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert got == want, (name, profile, reads[0])
