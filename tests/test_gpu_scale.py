@@ -206,3 +206,57 @@ def test_many_near_identical_strains_general_fold(tmp_path):
         assert idx.format_tsv("r", res[i], mat) == o.format("r", ores[i]), i
     o.close()
     assert float((res["n_match"] > 0).mean()) > 0.99
+
+
+def test_ragged_reads_fuzz_against_oracle(world, tmp_path):
+    """Reads of every length from 1 to 300 at every alignment of the flat buffer (the 16-byte packed blocks and the
+    64-character register queue of the search kernel see every phase), with substitutions, N, lower case, pure noise, mates
+    of different lengths; all fields against the C oracle."""
+    import torch
+    from centrifuger_amd import indexbuild
+    rng = np.random.default_rng(2024)
+    g = synth.make_genomes(6, 3, 40_000, seed=515)
+    prefix = str(tmp_path / "fz")
+    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=8, device=torch.device("cuda"))
+    cat = np.concatenate(g.seqs)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+
+    def make(n):
+        chunks, offs = [], [0]
+        for _ in range(n):
+            L = int(rng.integers(1, 301))
+            kind = rng.random()
+            if kind < 0.08:
+                r = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)].copy()      # noise
+            else:
+                p = int(rng.integers(0, len(cat) - L))
+                r = cat[p:p + L].copy()
+                if rng.random() < 0.5:
+                    r = comp[r[::-1]]
+                nsub = rng.binomial(L, 0.02)
+                pos = rng.integers(0, L, size=nsub)
+                r[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=nsub)]
+            if kind > 0.9:
+                r[rng.integers(0, L, size=max(1, L // 20))] = ord("N")
+            if 0.5 < kind < 0.55:
+                r = np.frombuffer(bytes(r).lower(), dtype=np.uint8).copy()                          # lower case is not a symbol
+            chunks.append(r)
+            offs.append(offs[-1] + L)
+        return np.concatenate(chunks), np.array(offs, dtype=np.uint64)
+
+    n = 12_000
+    b1, o1 = make(n)
+    b2, o2 = make(n)
+    for k in (1, 3):
+        idx, dev = _open(prefix, k)
+        o = ora.OracleIndex(prefix, max_result=k)
+        for pe in (False, True):
+            res, mat = dev.classify(b1, o1, b2 if pe else None, o2 if pe else None)
+            ores = o.classify(b1, o1, b2 if pe else None, o2 if pe else None, threads=16)
+            for i in range(n):
+                assert idx.format_tsv("r", res[i], mat) == o.format("r", ores[i]), (k, pe, i, int(o1[i + 1] - o1[i]))
+            assert 0.5 < float((res["n_match"] > 0).mean()) < 1.0
+        o.close()
+        dev.close()
