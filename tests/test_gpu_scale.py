@@ -260,3 +260,28 @@ def test_ragged_reads_fuzz_against_oracle(world, tmp_path):
             assert 0.5 < float((res["n_match"] > 0).mean()) < 1.0
         o.close()
         dev.close()
+
+
+def test_very_long_read_among_short_ones(world):
+    """One 400 kbp read (two genomes glued, 5 % errors) between ordinary reads: per-chain capacities, the pool of the general
+    fold and the 32-bit offsets inside a read all get a large value; fields against the oracle."""
+    rng = np.random.default_rng(9)
+    rs = world["reads"]
+    short_b, short_o = rs.bases[:150 * 50], rs.offsets[:51]
+    lg = world["long"]
+    big = np.concatenate([lg.bases[int(lg.offsets[i]):int(lg.offsets[i + 1])] for i in range(60)])[:400_000].copy()
+    pos = rng.integers(0, len(big), size=len(big) // 20)
+    big[pos] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=len(pos))]
+    b = np.concatenate([short_b[:150 * 25], big, short_b[150 * 25:]])
+    o = np.concatenate([short_o[:26], [short_o[25] + len(big)], short_o[26:] + len(big)]).astype(np.uint64)
+    assert int(o[-1]) == len(b) and len(o) == 52
+    for k in (1, 5):
+        idx, dev = _open(world["prefix"], k)
+        res, mat = dev.classify(b, o)
+        orc = ora.OracleIndex(world["prefix"], max_result=k)
+        ores = orc.classify(b, o, threads=4)
+        for i in range(51):
+            assert idx.format_tsv("r", res[i], mat) == orc.format("r", ores[i]), (k, i)
+        assert res[25]["query_length"] == len(big) and res[25]["n_match"] > 0
+        orc.close()
+        dev.close()
