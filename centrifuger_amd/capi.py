@@ -48,7 +48,7 @@ MATCH_DTYPE = np.dtype([("id", "<u8"), ("taxid", "<u8"), ("kind", "<i4"), ("pad"
 EXPORTS = [
     "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
-    "cfr_device_index_destroy", "cfr_device_index_get_info",
+    "cfr_device_index_destroy", "cfr_device_index_get_info", "cfr_device_index_set_dust", "cfr_dust_mask_device",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
@@ -187,6 +187,18 @@ class DeviceIndex:
         info = IndexInfo()
         _check(lib().cfr_device_index_get_info(self._d, C.byref(info)))
         return info
+
+    def set_dust(self, on: bool):
+        """SDUST on the device before every following classify call (the caller hands over unmasked reads)."""
+        _check(lib().cfr_device_index_set_dust(self._d, C.c_int(1 if on else 0)))
+
+    def dust_mask(self, bases, offsets):
+        """The device SDUST scan alone: masks `bases` (uint8 numpy, host) in place; returns the number of host fallbacks."""
+        assert bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"] and bases.flags["WRITEABLE"]
+        offsets = _u64(offsets)
+        nf = C.c_uint64(0)
+        _check(lib().cfr_dust_mask_device(self._d, _p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.byref(nf)))
+        return int(nf.value)
 
     def close(self):
         if self._d:

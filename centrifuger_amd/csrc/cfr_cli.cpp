@@ -467,7 +467,10 @@ int main(int argc, char *argv[]) {
   });
 
   // dust stage (CentrifugerClass.cpp:276-316): needs no index either
-  WorkerPool dust_pool(opt.threads), format_pool(opt.threads);
+  // The masking itself runs on the device inside the classify call (cfr_device_index_set_dust); the host stage only works
+  // when the masked reads are needed on the host as well (--un / --cl write them).
+  const bool host_dust = opt.dust && (!opt.un_prefix.empty() || !opt.cl_prefix.empty());
+  WorkerPool dust_pool(host_dust ? opt.threads : 1), format_pool(opt.threads);
   std::thread duster([&]() {
     for (;;) {
       std::shared_ptr<Batch> b;
@@ -479,7 +482,7 @@ int main(int argc, char *argv[]) {
         pending.pop_front();
       }
       const auto ts = tick();
-      if (opt.dust) {      // slices of the batch on the stage's own workers (offsets are absolute, so a slice is just an offset window)
+      if (opt.dust && host_dust) {      // slices of the batch on the stage's own workers (offsets are absolute, so a slice is just an offset window)
         const int parts = (int)std::min<size_t>((size_t)dust_pool.size(), std::max<size_t>(1, b->n / 2048));
         dust_pool.run(parts, [&](int t) {
           const size_t lo = b->n * (size_t)t / (size_t)parts, hi = b->n * (size_t)(t + 1) / (size_t)parts;
@@ -522,6 +525,7 @@ int main(int argc, char *argv[]) {
     cfr_dev_index *d = nullptr;
     st = cfr_device_index_create_ex(idx, g, &dopt, &d);
     if (st != CFR_OK) die_status("creating the device index (this build has no CPU fallback)", st);
+    if (opt.dust && !host_dust) cfr_device_index_set_dust(d, 1);
     devs.push_back(d);
   }
   if (devs.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }

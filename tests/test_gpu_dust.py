@@ -1,0 +1,117 @@
+"""SDUST on the device (k_dust) against the host twin (cfr_dust_mask_batch, itself pinned to the oracle and through it to the
+reference's Dustmasker): byte-identical masks on random, low-complexity and adversarial reads, and classification with the
+device pre-step == host pre-step + classification.  -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from centrifuger_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(rng, n):
+    """A mix that exercises every part of the scan: random DNA, homopolymers, di/tri-nucleotide repeats, biased composition,
+    N runs shorter and longer than the window, lower case, reads shorter than a triplet."""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(0, 400))
+        kind = i % 10
+        if kind == 0:
+            r = acgt[rng.integers(0, 4, size=L)]
+        elif kind == 1:
+            r = np.full(L, acgt[rng.integers(0, 4)], dtype=np.uint8)
+        elif kind == 2:
+            unit = acgt[rng.integers(0, 4, size=int(rng.integers(2, 7)))]
+            r = np.resize(unit, L)
+        elif kind == 3:
+            r = acgt[rng.choice(4, size=L, p=[0.85, 0.05, 0.05, 0.05])]
+        elif kind == 4:
+            r = acgt[rng.integers(0, 4, size=L)].copy()
+            if L > 40:
+                a = int(rng.integers(0, L - 30))
+                r[a:a + int(rng.integers(5, 30))] = ord("A")
+        elif kind == 5:
+            r = acgt[rng.integers(0, 4, size=L)].copy()
+            if L > 100:
+                a = int(rng.integers(0, L - 90))
+                r[a:a + int(rng.integers(1, 90))] = ord("N")        # runs below and above the 64-base window
+        elif kind == 6:
+            r = np.frombuffer(bytes(acgt[rng.choice(4, size=L, p=[0.7, 0.1, 0.1, 0.1])]).lower(), dtype=np.uint8)
+        elif kind == 7:
+            r = acgt[rng.choice(2, size=L)]
+        elif kind == 8:
+            r = np.concatenate([np.full(L // 2, ord("T"), dtype=np.uint8), acgt[rng.integers(0, 4, size=L - L // 2)]])
+        else:
+            r = acgt[rng.integers(0, 4, size=min(L, 2))]
+        out.append(np.ascontiguousarray(r, dtype=np.uint8))
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in out])]).astype(np.uint64)
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8), offs
+
+
+@pytest.fixture(scope="module")
+def dev(golden_dir):
+    idx = capi.Index(os.path.join(golden_dir, "f6"), capi.default_params(max_result=3))
+    d = capi.DeviceIndex(idx)
+    yield idx, d
+    d.close()
+
+
+def test_device_masks_equal_host_masks(dev):
+    _, d = dev
+    rng = np.random.default_rng(77)
+    b, o = _reads(rng, 30_000)
+    host = b.copy()
+    capi.dust_mask(host, o, threads=8)
+    got = b.copy()
+    nf = d.dust_mask(got, o)
+    assert np.array_equal(got, host)
+    assert int((host != b).sum()) > 100_000          # the mix really has low-complexity sequence
+    assert nf == 0 or nf < 100
+
+
+def test_unbounded_interval_list_falls_back_to_the_host_twin(dev):
+    """A 6 kbp homopolymer drives the reference's list of perfect intervals far past the device scratch (256 per lane): those
+    reads must come back masked by the host twin, the others by the kernel, all equal to the host masks."""
+    _, d = dev
+    rng = np.random.default_rng(78)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = [np.full(6000, ord("A"), dtype=np.uint8), acgt[rng.integers(0, 4, size=300)], np.resize(np.frombuffer(b"AC", dtype=np.uint8), 5000),
+             acgt[rng.integers(0, 4, size=150)], np.full(3000, ord("G"), dtype=np.uint8)]
+    b = np.concatenate(reads)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    host = b.copy()
+    capi.dust_mask(host, o, threads=1)
+    got = b.copy()
+    nf = d.dust_mask(got, o)
+    assert np.array_equal(got, host)
+    assert nf >= 1
+
+
+def test_classification_with_the_device_pre_step(dev, golden_dir):
+    """set_dust(1): unmasked reads in, same results as host masking + classification; the caller's buffer is not modified."""
+    idx, d = dev
+    recs = open(os.path.join(golden_dir, "se.fq"), "rb").read().split(b"\n")
+    seqs = [recs[i + 1] for i in range(0, len(recs) - 1, 4)]
+    rng = np.random.default_rng(3)
+    seqs += [b"A" * 120 + bytes(rng.choice(list(b"ACGT"), size=60).astype(np.uint8)) for _ in range(50)] + [b"ACACACACAC" * 15] * 5
+    b = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    o = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    masked = b.copy()
+    capi.dust_mask(masked, o, threads=4)
+    want_r, want_m = d.classify(masked, o)
+    d.set_dust(True)
+    try:
+        keep = b.copy()
+        got_r, got_m = d.classify(b, o)
+        assert np.array_equal(b, keep)
+        assert got_r.tobytes() == want_r.tobytes() and got_m.tobytes() == want_m.tobytes()
+        # paired entry with the same reads as mates
+        gp_r, gp_m = d.classify(b, o, b, o)
+    finally:
+        d.set_dust(False)
+    wp_r, wp_m = d.classify(masked, o, masked, o)
+    assert gp_r.tobytes() == wp_r.tobytes() and gp_m.tobytes() == wp_m.tobytes()
+    assert int((masked != b).sum()) > 1000
