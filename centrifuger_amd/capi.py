@@ -193,12 +193,10 @@ class DeviceIndex:
         _check(lib().cfr_device_index_set_dust(self._d, C.c_int(1 if on else 0)))
 
     def dust_mask(self, bases, offsets):
-        """The device SDUST scan alone: masks `bases` (uint8 numpy, host) in place; returns the number of host fallbacks."""
+        """The device SDUST scan alone: masks `bases` (uint8 numpy, host) in place."""
         assert bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"] and bases.flags["WRITEABLE"]
         offsets = _u64(offsets)
-        nf = C.c_uint64(0)
-        _check(lib().cfr_dust_mask_device(self._d, _p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.byref(nf)))
-        return int(nf.value)
+        _check(lib().cfr_dust_mask_device(self._d, _p(bases), _p(offsets), C.c_size_t(len(offsets) - 1)))
 
     def close(self):
         if self._d:

@@ -215,11 +215,10 @@ cfr_status cfr_device_index_set_dust(cfr_dev_index *d, int on) {
   d->d->set_dust(on != 0);
   return CFR_OK;
 }
-cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n, uint64_t *n_host_fallback) {
+cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n) {
   if (!d || (n && (!bases || !offsets))) return bad_arg("cfr_dust_mask_device: null argument");
   return guarded([&]() -> cfr_status {
     d->d->dust_mask_host(bases, offsets, n);
-    if (n_host_fallback) *n_host_fallback = d->d->dust_fallbacks();
     return CFR_OK;
   });
 }

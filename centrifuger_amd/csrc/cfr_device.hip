@@ -25,7 +25,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTCTL, S_DUSTTMP, S_DUSTTMP2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -595,38 +595,13 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
 }
 
 // SDUST (the reference's pre-step of Query, CentrifugerClass.cpp:276-316) on reads that are already in HBM: masks d_bases in
-// place.  The reference's list of perfect intervals has no bound; a read that needs more than kDustCap entries comes back
-// flagged and is masked here on the host - from the caller's unmasked host bases (h_orig, with h_offs) or, without those,
-// from the unmasked device copy d_orig - and written over whatever the kernel had done to it.  One host sync.
-void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, const uint8_t *h_orig, const uint64_t *h_offs,
-                                 const uint8_t *d_orig, hipStream_t st) {
+// place, asynchronously on `st` (k_dust; bounded per-lane state, no host involvement).
+void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, hipStream_t st) {
   if (n == 0) return;
   const unsigned blocks = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
-  const uint64_t flag_cap = 1u << 16;
-  DustIv *pool = (DustIv *)scratch(S_DUSTPOOL, (size_t)blocks * kDustBlock * kDustCap * sizeof(DustIv));
-  unsigned long long *ctl = (unsigned long long *)scratch(S_DUSTCTL, (1 + flag_cap) * 8);
-  HIP_CHECK(hipMemsetAsync(ctl, 0, 8, st));
-  k_dust<<<blocks, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool, ctl, (uint64_t *)(ctl + 1), flag_cap);
+  uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2, (size_t)blocks * kDustBlock * 64 * sizeof(uint32_t));   // one table per stream
+  k_dust<<<blocks, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool);
   HIP_CHECK(hipGetLastError());
-  unsigned long long cnt = 0;
-  HIP_CHECK(hipMemcpyAsync(&cnt, ctl, 8, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipStreamSynchronize(st));
-  if (cnt == 0) return;
-  if (cnt > flag_cap) throw HipError{"SDUST: too many reads with very long low-complexity stretches in one batch", -5};
-  std::vector<uint64_t> idx(cnt), off(2);
-  HIP_CHECK(hipMemcpy(idx.data(), ctl + 1, cnt * 8, hipMemcpyDeviceToHost));
-  std::vector<uint8_t> buf;
-  for (uint64_t r : idx) {
-    if (h_offs) { off[0] = h_offs[r]; off[1] = h_offs[r + 1]; }
-    else HIP_CHECK(hipMemcpy(off.data(), d_offs + r, 16, hipMemcpyDeviceToHost));
-    const size_t len = (size_t)(off[1] - off[0]);
-    buf.resize(len);
-    if (h_orig) memcpy(buf.data(), h_orig + off[0], len);
-    else HIP_CHECK(hipMemcpy(buf.data(), d_orig + off[0], len, hipMemcpyDeviceToHost));
-    dust_mask(buf.data(), len);
-    HIP_CHECK(hipMemcpy(d_bases + off[0], buf.data(), len, hipMemcpyHostToDevice));
-  }
-  last_dust_fallbacks_ += cnt;
 }
 
 void DeviceIndex::dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n) {
@@ -637,10 +612,9 @@ void DeviceIndex::dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n)
   uint64_t *d_o = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
   if (total) HIP_CHECK(hipMemcpyAsync(d_b, bases, total, hipMemcpyHostToDevice, stream_));
   HIP_CHECK(hipMemcpyAsync(d_o, offs, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
-  last_dust_fallbacks_ = 0;
-  std::vector<uint8_t> orig(bases, bases + total);           // the fallback masks from the unmasked bases
-  dust_on_device(d_b, d_o, n, orig.data(), offs, nullptr, stream_);
-  if (total) HIP_CHECK(hipMemcpy(bases, d_b, total, hipMemcpyDeviceToHost));
+  dust_on_device(d_b, d_o, n, stream_);
+  if (total) HIP_CHECK(hipMemcpyAsync(bases, d_b, total, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 // 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
@@ -750,7 +724,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     auto masked_copy = [&](size_t slot, const uint8_t *d_b, const uint64_t *d_o, uint64_t total) -> const uint8_t * {
       uint8_t *c = (uint8_t *)scratch(slot, total + 16);
       if (total) HIP_CHECK(hipMemcpyAsync(c, d_b, total, hipMemcpyDeviceToDevice, stream_));
-      dust_on_device(c, d_o, n, nullptr, nullptr, d_b, stream_);
+      dust_on_device(c, d_o, n, stream_);
       return c;
     };
     d_b1 = masked_copy(S_DUSTTMP, d_b1, d_o1, total1);
@@ -775,8 +749,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     one(src->b1, src->o1, d_b1);
     if (paired) one(src->b2, src->o2, d_b2);
     if (dust_) {       // masked on the copy stream, under the kernels of the previous piece
-      dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, src->b1, src->o1 + lo, nullptr, h2d_stream_);
-      if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, src->b2, src->o2 + lo, nullptr, h2d_stream_);
+      dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, h2d_stream_);
+      if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, h2d_stream_);
     }
     HIP_CHECK(hipEventRecord(h2d_done_[k], h2d_stream_));
     have_piece[k] = 1;

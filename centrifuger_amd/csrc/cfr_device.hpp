@@ -134,7 +134,6 @@ class DeviceIndex {
   // SDUST before the search of every classify call (off by default: the C-ABI contract is "already masked if the caller wants dust")
   void set_dust(bool on) { dust_ = on; }
   bool dust() const { return dust_; }
-  uint64_t dust_fallbacks() const { return last_dust_fallbacks_; }
   // host buffers in/out: the device scan as a stand-alone entry (parity probe of k_dust)
   void dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n);
 
@@ -154,8 +153,7 @@ class DeviceIndex {
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                    bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
   std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb) const;
-  void dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, const uint8_t *h_orig, const uint64_t *h_offs,
-                      const uint8_t *d_orig, hipStream_t st);
+  void dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, hipStream_t st);
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
@@ -180,7 +178,6 @@ class DeviceIndex {
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false;
-  uint64_t last_dust_fallbacks_ = 0;
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;

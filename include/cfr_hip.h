@@ -194,10 +194,9 @@ cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n
 /* The same masking on the device.  cfr_device_index_set_dust(d, 1): every following cfr_classify_batch /
  * cfr_classify_batch_resident call on d masks its reads in HBM before searching them (the caller's buffers are not modified),
  * so unmasked reads can be handed over and the host pre-step disappears; results equal cfr_dust_mask_batch + classify.
- * cfr_dust_mask_device: the device scan alone, host buffer in and out (parity probe; *n_host_fallback, if not NULL, receives the
- * number of reads whose interval list outgrew the device scratch and were masked by the host twin instead). */
+ * cfr_dust_mask_device: the device scan alone, host buffer in and out (parity probe). */
 cfr_status cfr_device_index_set_dust(cfr_dev_index *d, int on);
-cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n, uint64_t *n_host_fallback);
+cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n);
 
 /* ResultWriter::Output rows for one read (ResultWriter.hpp:209-240).  Returns bytes needed; writes at most cap. */
 size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches,

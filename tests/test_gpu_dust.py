@@ -66,15 +66,14 @@ def test_device_masks_equal_host_masks(dev):
     host = b.copy()
     capi.dust_mask(host, o, threads=8)
     got = b.copy()
-    nf = d.dust_mask(got, o)
+    d.dust_mask(got, o)
     assert np.array_equal(got, host)
     assert int((host != b).sum()) > 100_000          # the mix really has low-complexity sequence
-    assert nf == 0 or nf < 100
 
 
-def test_unbounded_interval_list_falls_back_to_the_host_twin(dev):
-    """A 6 kbp homopolymer drives the reference's list of perfect intervals far past the device scratch (256 per lane): those
-    reads must come back masked by the host twin, the others by the kernel, all equal to the host masks."""
+def test_long_homopolymers_and_repeats(dev):
+    """A 6 kbp homopolymer drives the reference's list of perfect intervals to its maximum (1711 entries, rescanned per window
+    suffix); the device keeps one entry per start instead and must still produce the same masks."""
     _, d = dev
     rng = np.random.default_rng(78)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -85,9 +84,8 @@ def test_unbounded_interval_list_falls_back_to_the_host_twin(dev):
     host = b.copy()
     capi.dust_mask(host, o, threads=1)
     got = b.copy()
-    nf = d.dust_mask(got, o)
+    d.dust_mask(got, o)
     assert np.array_equal(got, host)
-    assert nf >= 1
 
 
 def test_classification_with_the_device_pre_step(dev, golden_dir):
