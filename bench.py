@@ -338,6 +338,16 @@ def main():
     from centrifuger_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist=dist, device=None if share_gpu else device)   # the job is as slow as its slowest rank
     classified = int((results["n_match"] > 0).sum())
+    # informational: the same step with the SDUST pre-step on the device (private copy of the reads + k_dust); never `value`
+    dev.set_dust(True)
+    step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    ms_with_dust = 1000.0 * (time.perf_counter() - t1)
+    dev.set_dust(False)
+    step()                                               # results of the plain step again (the checks below read them)
     os.sched_setaffinity(0, all_cpus)                    # the CPU legs below (oracle counters, reference baseline) get every core back
 
     if rank != 0:
@@ -359,6 +369,7 @@ def main():
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
                    "numa_node_of_rank0": numa},
         "classified_fraction": classified / args.reads,
+        "ms_per_step_with_device_sdust": ms_with_dust,
         "stage_ms": {k: float(np.mean([getattr(s, k) for s in kstats])) for k in
                      ("pack_ms", "search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")},
     }
