@@ -49,6 +49,7 @@ EXPORTS = [
     "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
     "cfr_device_index_destroy", "cfr_device_index_get_info", "cfr_device_index_set_dust", "cfr_dust_mask_device",
+    "cfr_dust_mask_batch_literal",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
@@ -301,11 +302,12 @@ def device_count() -> int:
     return c.value if st == CFR_OK else 0
 
 
-def dust_mask(bases, offsets, threads=1):
-    """In-place SDUST masking of a flat read buffer (cfr_dust_mask_batch)."""
+def dust_mask(bases, offsets, threads=1, literal=False):
+    """In-place SDUST masking of a flat read buffer (cfr_dust_mask_batch; literal=True: the reference's own data structure)."""
     assert bases.dtype == np.uint8 and bases.flags["C_CONTIGUOUS"] and bases.flags["WRITEABLE"]
     offsets = _u64(offsets)
-    _check(lib().cfr_dust_mask_batch(_p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.c_int(threads)))
+    fn = lib().cfr_dust_mask_batch_literal if literal else lib().cfr_dust_mask_batch
+    _check(fn(_p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.c_int(threads)))
     return bases
 
 

@@ -193,13 +193,13 @@ cfr_status cfr_last_batch_stats(const cfr_dev_index *d, cfr_batch_stats *st) {
   return CFR_OK;
 }
 
-cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads) {
+static cfr_status dust_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads, void (*mask)(uint8_t *, size_t)) {
   if (n && (!bases || !offsets)) return bad_arg("cfr_dust_mask_batch: null argument");
   if (threads < 1) threads = 1;
   auto work = [&](int tid) {
     // a contiguous slice per thread (reads are independent; the reference strides them, the result is the same)
     const size_t lo = n * (size_t)tid / (size_t)threads, hi = n * (size_t)(tid + 1) / (size_t)threads;
-    for (size_t i = lo; i < hi; ++i) cfr::dust_mask(bases + offsets[i], offsets[i + 1] - offsets[i]);
+    for (size_t i = lo; i < hi; ++i) mask(bases + offsets[i], offsets[i + 1] - offsets[i]);
   };
   if (threads == 1) work(0);
   else {
@@ -208,6 +208,12 @@ cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n
     for (auto &x : th) x.join();
   }
   return CFR_OK;
+}
+cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads) {
+  return dust_batch(bases, offsets, n, threads, cfr::dust_mask);
+}
+cfr_status cfr_dust_mask_batch_literal(uint8_t *bases, const uint64_t *offsets, size_t n, int threads) {
+  return dust_batch(bases, offsets, n, threads, cfr::dust_mask_literal);
 }
 
 cfr_status cfr_device_index_set_dust(cfr_dev_index *d, int on) {

@@ -875,13 +875,15 @@ void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uin
     const uint64_t t1 = o1[n], t2 = b2 ? o2[n] : 0;
     uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, t1 + 16);
     uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
-    HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+    // the offsets travel on the same stream as the bases: the SDUST kernel of a piece runs there and reads them, and the
+    // main stream only touches a piece behind that stream's event
+    HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
     uint8_t *d_b2 = nullptr;
     uint64_t *d_o2 = nullptr;
     if (b2) {
       d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 16);
       d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
-      HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+      HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
     }
     classify_device(d_b1, d_o1, d_b2, d_o2, n, t1, t2, results, matches, match_cap, match_extent, &src);
     return;

@@ -18,7 +18,8 @@ void classify_batch_tail(const HostIndex &h, const DeviceIndex::BatchOut &b, siz
 
 const char *tax_rank_string(uint8_t rank);
 
-// SDUST pre-step (cfr_dust.cpp)
+// SDUST pre-step (cfr_dust.cpp): the production form (bounded state) and the literal form of the reference's scan
 void dust_mask(uint8_t *s, size_t n);
+void dust_mask_literal(uint8_t *s, size_t n);
 
 }  // namespace cfr

@@ -190,6 +190,9 @@ cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, con
 /* ---- host helpers around the path ---- */
 /* SDUST pre-step (Dustmasker.hpp:357-421 + CentrifugerClass.cpp:283-289): masked bases -> 'N', in place */
 cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads);
+/* the same masks computed with the reference's data structure as it is (a list of perfect intervals that reaches 1711 entries on a
+ * homopolymer and is rescanned per window suffix: milliseconds per poly-A read); the anchor the two fast forms are tested against */
+cfr_status cfr_dust_mask_batch_literal(uint8_t *bases, const uint64_t *offsets, size_t n, int threads);
 
 /* The same masking on the device.  cfr_device_index_set_dust(d, 1): every following cfr_classify_batch /
  * cfr_classify_batch_resident call on d masks its reads in HBM before searching them (the caller's buffers are not modified),

@@ -323,3 +323,49 @@ def test_index_written_before_the_end_marker_field(golden_dir, tmp_path, oracle_
         with pytest.raises(capi.CfrError) as e:
             capi.Index(str(tmp_path / "old"))
         assert e.value.status in (capi.CFR_ERR_FORMAT, capi.CFR_ERR_IO)
+
+
+def test_bounded_dust_equals_the_literal_scan():
+    """cfr_dust_mask_batch runs the bounded form of the scan (one slot per interval start); the literal form keeps the
+    reference's list.  Same masks on random, low-complexity and adversarial reads, and the bounded form does not blow up on
+    homopolymers (the literal one takes milliseconds per poly-A read)."""
+    import time
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    reads = []
+    for i in range(6000):
+        L = int(rng.integers(0, 400))
+        kind = i % 8
+        if kind == 0:
+            r = acgt[rng.integers(0, 4, size=L)]
+        elif kind == 1:
+            r = np.full(L, acgt[rng.integers(0, 4)], dtype=np.uint8)
+        elif kind == 2:
+            r = np.resize(acgt[rng.integers(0, 4, size=int(rng.integers(2, 7)))], L)
+        elif kind == 3:
+            r = acgt[rng.choice(4, size=L, p=[0.85, 0.05, 0.05, 0.05])]
+        elif kind == 4:
+            r = acgt[rng.integers(0, 4, size=L)].copy()
+            if L > 100:
+                a = int(rng.integers(0, L - 90))
+                r[a:a + int(rng.integers(1, 90))] = ord("N")
+        elif kind == 5:
+            r = acgt[rng.choice(2, size=L)]
+        elif kind == 6:
+            r = np.concatenate([np.full(L // 2, ord("T"), dtype=np.uint8), acgt[rng.integers(0, 4, size=L - L // 2)]])
+        else:
+            r = np.frombuffer(bytes(acgt[rng.choice(4, size=L, p=[0.7, 0.1, 0.1, 0.1])]).lower(), dtype=np.uint8)
+        reads.append(np.ascontiguousarray(r, dtype=np.uint8))
+    reads.append(np.full(5000, ord("A"), dtype=np.uint8))
+    reads.append(np.resize(np.frombuffer(b"ACG", dtype=np.uint8), 4000))
+    b = np.concatenate(reads)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.uint64)
+    t0 = time.perf_counter()
+    fast = capi.dust_mask(b.copy(), o, threads=4)
+    t_fast = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lit = capi.dust_mask(b.copy(), o, threads=4, literal=True)
+    t_lit = time.perf_counter() - t0
+    assert np.array_equal(fast, lit)
+    assert int((lit != b).sum()) > 100_000
+    assert t_fast < t_lit
