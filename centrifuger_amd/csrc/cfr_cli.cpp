@@ -140,16 +140,23 @@ class SeqReader {
     if (ids) { ids->insert(ids->end(), p + 1, p + 1 + idn); ids->push_back('\0'); }
     has_qual = false;
     size_t seq_n = 0;
+    // kseq's grammar (kseq.h kseq_read): the sequence runs until a line that starts with '>', '@' or '+', whatever the
+    // header character was and however many bases have been read; a '+' line switches to the quality block, which is
+    // read line by line until it is at least as long as the sequence (at least one line, also for an empty sequence).
+    (void)fastq;
     while (next_line(p, n)) {
       if (n == 0) continue;
-      if (p[0] == '>' || (!fastq && p[0] == '@')) { header_.assign(p, n); have_header_ = true; return true; }
-      if (fastq && p[0] == '+') {
+      if (p[0] == '>' || p[0] == '@') { header_.assign(p, n); have_header_ = true; return true; }
+      if (p[0] == '+') {
         has_qual = true;
         size_t qn = 0;
-        while (qn < seq_n && next_line(p, n)) { if (qual) qual->insert(qual->end(), p, p + n); qn += n; }
+        do {
+          if (!next_line(p, n)) break;
+          if (qual) qual->insert(qual->end(), p, p + n);
+          qn += n;
+        } while (qn < seq_n);
         return true;
       }
-      if (fastq && p[0] == '@' && seq_n) { header_.assign(p, n); have_header_ = true; return true; }
       seq.insert(seq.end(), (const uint8_t *)p, (const uint8_t *)p + n);
       seq_n += n;
     }
@@ -354,6 +361,11 @@ int main(int argc, char *argv[]) {
   const bool paired = !opt.m1.empty() || !opt.inter.empty();
   if (opt.m1.size() != opt.m2.size()) { print_log("ERROR: -1 and -2 must be given the same number of times."); return EXIT_FAILURE; }
   if (opt.u.empty() && !paired) { print_log("Need to use -u/-1/-2/-i to specify input reads."); return EXIT_FAILURE; }
+  if ((int)!opt.u.empty() + (int)!opt.m1.empty() + (int)!opt.inter.empty() > 1) {
+    // the reference would walk a mixed file list; this build processes one kind of input per run and says so instead of dropping files
+    print_log("ERROR: -u, -1/-2 and -i cannot be combined in one run of this build.");
+    return EXIT_FAILURE;
+  }
 
   if (const char *e = getenv("CFR_CLI_PARSE_ONLY")) if (atoi(e)) {
     // parser self-test hook (tests/test_host_cpu.py): records as "id<TAB>bases[<TAB>mate bases]<TAB>q|-" lines; no index, no device
@@ -394,7 +406,14 @@ int main(int argc, char *argv[]) {
   ReadDump un, cl;
   if (!opt.un_prefix.empty()) un.open(opt.un_prefix, paired);
   if (!opt.cl_prefix.empty()) cl.open(opt.cl_prefix, paired);
-  fputs(cfr_tsv_header(), stdout);
+  if (!opt.all_gpus && opt.gpus.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }
+  if (opt.all_gpus) {
+    int cnt = 0;
+    cfr_device_count(&cnt);
+    opt.gpus.clear();
+    for (int g = 0; g < cnt; ++g) opt.gpus.push_back(g);
+    if (opt.gpus.empty()) { print_log("ERROR: no MI355X device found (this build has no CPU fallback)."); return EXIT_FAILURE; }
+  }
 
   // ---- pipeline: reader -> dust -> device workers (one per GPU) -> TSV formatter -> ordered writer (this thread)
   std::mutex mu;
@@ -510,12 +529,6 @@ int main(int argc, char *argv[]) {
   cfr_index_get_info(idx, &info);
   print_log("Finishes loading index.");
   if (opt.params.min_hit_len <= 0) print_log("Inferred --min-hitlen: %d", info.min_hit_len);
-  if (opt.all_gpus) {
-    int cnt = 0;
-    cfr_device_count(&cnt);
-    opt.gpus.clear();
-    for (int g = 0; g < cnt; ++g) opt.gpus.push_back(g);
-  }
   std::vector<cfr_dev_index *> devs;
   t0 = tick();
   cfr_device_options dopt;
@@ -528,8 +541,8 @@ int main(int argc, char *argv[]) {
     if (opt.dust && !host_dust) cfr_device_index_set_dust(d, 1);
     devs.push_back(d);
   }
-  if (devs.empty()) { print_log("ERROR: no MI355X device selected."); return EXIT_FAILURE; }
   clk.add(T_DEVICE, t0);
+  fputs(cfr_tsv_header(), stdout);          // only once the index and the devices are up: a failed load prints no TSV at all
 
 
   // device stage: one thread per GPU takes dust-masked batches

@@ -58,10 +58,24 @@ void *DeviceIndex::scratch(size_t slot, size_t bytes) {
   return s.p;
 }
 
+// A constructor that throws never runs the destructor: everything the image owns is released here before the error leaves
+// (a bad argument from a library caller must not strand tens of GB of HBM until the process exits).
 DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_options &opt) : host_(&h), device_(device) {
+  // arguments first, before anything is allocated
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"no HIP device available (libcfr_hip has no CPU fallback)", -1};
   if (device < 0 || device >= count) throw HipError{"device ordinal out of range", -1};
+  if (h.params.max_result > 64) throw HipError{"-k / max_result above 64 is not supported by the device tail", -2};
+  try {
+    init(h, opt);
+  } catch (...) {
+    release();
+    throw;
+  }
+}
+
+void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
+  const int device = device_;
   HIP_CHECK(hipSetDevice(device));
   HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   for (auto &set : evs_) for (auto &e : set) HIP_CHECK(hipEventCreate(&e));
@@ -127,8 +141,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
           ones += (uint64_t)__builtin_popcountll(w);
         }
       }
-      uint64_t *d = nullptr;
-      HIP_CHECK(hipMalloc((void **)&d, L.size() * 8));
+      uint64_t *d = (uint64_t *)temp_alloc(L.size() * 8);
       rb_allocs.push_back(d);
       HIP_CHECK(hipMemcpy(d, L.data(), L.size() * 8, hipMemcpyHostToDevice));
       return RankLines{d, bv.n};
@@ -146,7 +159,7 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
     view_.rb.filter_rate = (uint32_t)h.selected_filter_rate;
     lap("rank lines (host) + upload");
     if (layout_rb) {
-      for (void *q : rb_allocs) owned_.push_back(q);
+      for (void *q : rb_allocs) { temps_.erase(std::find(temps_.begin(), temps_.end(), q)); owned_.push_back(q); }
       if (!h.selected_rows.empty()) {
         std::vector<uint64_t> filt(((h.n + view_.rb.filter_rate - 1) / view_.rb.filter_rate + 63) / 64 + 1, 0);
         for (uint64_t r : h.selected_rows) { const uint64_t fb = r / view_.rb.filter_rate; filt[fb >> 6] |= 1ull << (fb & 63); }
@@ -158,35 +171,31 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
       // ---- occ records: 64 B per 128 symbols (layout in cfr_device.hpp), expanded from the image above
       const uint64_t nrec = (h.n >> 7) + 2, halves = nrec * 2;
       d_occ = dev_alloc<uint64_t>(nrec * 8);
-      uint64_t *d_cnt = nullptr, *d_pre = nullptr;
-      HIP_CHECK(hipMalloc((void **)&d_cnt, 3 * (halves + 1) * 8));
-      HIP_CHECK(hipMalloc((void **)&d_pre, 3 * (halves + 1) * 8));
+      uint64_t *d_cnt = (uint64_t *)temp_alloc(3 * (halves + 1) * 8), *d_pre = (uint64_t *)temp_alloc(3 * (halves + 1) * 8);
       HIP_CHECK(hipMemsetAsync(d_cnt, 0, 3 * (halves + 1) * 8, stream_));
       const unsigned g = (unsigned)std::min<uint64_t>((halves + 255) / 256, 1u << 20);
       k_occ_expand<<<g, 256, 0, stream_>>>(view_.rb, h.n, halves, d_occ, d_cnt);
       HIP_CHECK(hipGetLastError());
       size_t tmp_bytes = 0;
       HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_cnt, d_pre, (int)(halves + 1), stream_));
-      void *d_tmp = nullptr;
-      HIP_CHECK(hipMalloc(&d_tmp, tmp_bytes));
+      void *d_tmp = temp_alloc(tmp_bytes);
       for (int c = 0; c < 3; ++c)
         HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_cnt + c * (halves + 1), d_pre + c * (halves + 1), (int)(halves + 1), stream_));
       k_occ_fill_mid<<<g, 256, 0, stream_>>>(halves, d_pre, d_occ);
       HIP_CHECK(hipGetLastError());
       if (!h.selected_rows.empty()) {
-        uint64_t *d_sel = nullptr;
-        HIP_CHECK(hipMalloc((void **)&d_sel, h.selected_rows.size() * 8));
+        uint64_t *d_sel = (uint64_t *)temp_alloc(h.selected_rows.size() * 8);
         HIP_CHECK(hipMemcpyAsync(d_sel, h.selected_rows.data(), h.selected_rows.size() * 8, hipMemcpyHostToDevice, stream_));
         k_occ_flag_selected<<<(unsigned)((h.selected_rows.size() + 255) / 256), 256, 0, stream_>>>(d_sel, h.selected_rows.size(), d_occ, kSelFlag);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(stream_));
-        HIP_CHECK(hipFree(d_sel));
+        temp_free(d_sel);
       }
       HIP_CHECK(hipStreamSynchronize(stream_));
-      HIP_CHECK(hipFree(d_tmp));
-      HIP_CHECK(hipFree(d_cnt));
-      HIP_CHECK(hipFree(d_pre));
-      for (void *q : rb_allocs) HIP_CHECK(hipFree(q));
+      temp_free(d_tmp);
+      temp_free(d_cnt);
+      temp_free(d_pre);
+      for (void *q : rb_allocs) temp_free(q);
       memset(&view_.rb, 0, sizeof(view_.rb));
       lap("occ expansion (device)");
     }
@@ -219,7 +228,6 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
   view_.sample_rate = (uint32_t)h.sample_rate;
   view_.min_hit_len = h.params.min_hit_len;
   view_.score_adjust = h.score_hit_len_adjust;
-  if (h.params.max_result > 64) throw HipError{"-k / max_result above 64 is not supported by the device tail", -2};
   view_.max_result = h.params.max_result;
   view_.tax_parent = upload(h.tax.parent);
   view_.tax_orig = upload(h.tax.orig_taxid);
@@ -335,18 +343,42 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }
 
-DeviceIndex::~DeviceIndex() {
+DeviceIndex::~DeviceIndex() { release(); }
+
+void DeviceIndex::release() {            // idempotent: also the clean-up of a constructor that failed half way
   (void)hipSetDevice(device_);
+  (void)hipDeviceSynchronize();
   for (void *p : owned_) (void)hipFree(p);
+  owned_.clear();
+  for (void *p : temps_) (void)hipFree(p);
+  temps_.clear();
   for (auto &s : slots_) if (s.p) (void)hipFree(s.p);
+  slots_.clear();
   if (pinned_) (void)hipHostFree(pinned_);
-  for (auto &set : evs_) for (auto &e : set) if (e) (void)hipEventDestroy(e);
-  for (auto &e : tail_done_) if (e) (void)hipEventDestroy(e);
-  for (auto &e : copy_done_) if (e) (void)hipEventDestroy(e);
-  for (auto &e : h2d_done_) if (e) (void)hipEventDestroy(e);
-  if (h2d_stream_) (void)hipStreamDestroy(h2d_stream_);
-  if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
-  if (stream_) (void)hipStreamDestroy(stream_);
+  pinned_ = nullptr; pinned_cap_ = 0;
+  auto drop_event = [](hipEvent_t &e) { if (e) (void)hipEventDestroy(e); e = nullptr; };
+  for (auto &set : evs_) for (auto &e : set) drop_event(e);
+  for (auto &e : tail_done_) drop_event(e);
+  for (auto &e : copy_done_) drop_event(e);
+  for (auto &e : h2d_done_) drop_event(e);
+  auto drop_stream = [](hipStream_t &s) { if (s) (void)hipStreamDestroy(s); s = nullptr; };
+  drop_stream(h2d_stream_);
+  drop_stream(copy_stream_);
+  drop_stream(stream_);
+}
+
+// load-time temporaries: registered in temps_ so that a throw anywhere in init() frees them (release()), freed early by temp_free
+void *DeviceIndex::temp_alloc(size_t bytes) {
+  void *p = nullptr;
+  HIP_CHECK(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+  temps_.push_back(p);
+  return p;
+}
+void DeviceIndex::temp_free(void *p) {
+  if (!p) return;
+  auto it = std::find(temps_.begin(), temps_.end(), p);
+  if (it != temps_.end()) temps_.erase(it);
+  (void)hipFree(p);
 }
 
 // ------------------------------------------------------------------------------------ probes

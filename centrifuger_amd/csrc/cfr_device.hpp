@@ -138,6 +138,10 @@ class DeviceIndex {
   void dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n);
 
  private:
+  void init(const HostIndex &h, const cfr_device_options &opt);
+  void release();
+  void *temp_alloc(size_t bytes);
+  void temp_free(void *p);
   template <class T> T *dev_alloc(size_t count);
   template <class T> T *upload(const std::vector<T> &v);
   struct Staged { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; uint64_t t1, t2; };
@@ -164,7 +168,7 @@ class DeviceIndex {
   int device_;
   hipStream_t stream_ = nullptr;
   DevView view_{};
-  std::vector<void *> owned_;
+  std::vector<void *> owned_, temps_;     // device allocations of the image / load-time temporaries still alive
   uint64_t device_bytes_ = 0;
   struct Slot { void *p = nullptr; size_t cap = 0; };
   std::vector<Slot> slots_;

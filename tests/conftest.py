@@ -19,11 +19,8 @@ def pytest_configure(config):
 def oracle_bin():
     """oracle/cfr_oracle (the plain-C restatement CLI); built on demand with gcc."""
     exe = os.path.join(ORACLE_DIR, "cfr_oracle")
-    src_newer = (not os.path.exists(exe)) or any(
-        os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(exe)
-        for f in ("cfr_oracle.c", "cfr_oracle.h", "cfr_oracle_main.c"))
-    if src_newer:
-        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
+    # always through make: it does the dependency check (file times of a fresh clone say nothing)
+    subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
     return exe
 
 

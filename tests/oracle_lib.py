@@ -54,9 +54,7 @@ def lib():
     global _lib
     if _lib is None:
         so = os.path.join(ORACLE_DIR, "liboracle.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("cfr_oracle.c", "cfr_oracle.h")]
-        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True, stdout=subprocess.DEVNULL)   # make does the dependency check
         L = C.CDLL(so)
         L.ora_index_load.restype = C.c_void_p
         L.ora_index_load.argtypes = [C.c_char_p, C.c_void_p]

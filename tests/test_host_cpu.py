@@ -222,7 +222,6 @@ def _py_parse(data: bytes):
         if not ln or ln[:1] not in (b">", b"@"):
             i += 1
             continue
-        fastq = ln[:1] == b"@"
         rid = ln[1:].split(b" ")[0].split(b"\t")[0]
         if len(rid) >= 2 and rid[-2:] in (b"/1", b"/2"):
             rid = rid[:-2]
@@ -233,16 +232,16 @@ def _py_parse(data: bytes):
             if not ln:
                 i += 1
                 continue
-            if ln[:1] == b">" or (not fastq and ln[:1] == b"@"):
+            if ln[:1] in (b">", b"@"):          # kseq: a header character at a line start ends the sequence, always
                 break
-            if fastq and ln[:1] == b"+":
+            if ln[:1] == b"+":                  # ... and '+' starts the quality block, whatever the header character was
                 hq = True
                 i += 1
-                while len(qual) < len(seq) and i < len(lines):
+                while i < len(lines):           # at least one line, then until as long as the sequence
                     qual += lines[i]
                     i += 1
-                break
-            if fastq and ln[:1] == b"@" and seq:
+                    if len(qual) >= len(seq):
+                        break
                 break
             seq += ln
             i += 1
@@ -270,6 +269,8 @@ def test_cli_read_parser(tmp_path, gz):
         "fastq_multiline": b"@m1\nACGT\nACGT\n+\nIIII\nIIII\n@m2\nAC\n+\nII\n",
         "mixed_blank": b"\n\n>f1\nAC\n\nGT\n@q1\nAAAA\n+\nIIII\n>f2\nCC\n",
         "long_record": b">big\n" + b"\n".join(dna(70) for _ in range(3000)) + b"\n>tail\nACGT\n",
+        "fastq_empty_sequence": b"@e1\n@e2\nACGT\n+\nIIII\n@e3\n+\n\n@e4\nGG\n+\nII\n",
+        "fasta_with_plus_line": b">f\nACGT\n+\nIIII\n>g\nCC\n",
         "huge_line": b">one\n" + dna(40_000_000 if not gz else 400_000) + b"\n>two\nAC\n",
     }
     for name, data in cases.items():
@@ -369,3 +370,21 @@ def test_bounded_dust_equals_the_literal_scan():
     assert np.array_equal(fast, lit)
     assert int((lit != b).sum()) > 100_000
     assert t_fast < t_lit
+
+
+def test_bench_gpus_flag_is_honoured():
+    """`bench.py --gpus N` must mean N ranks: a launcher that started a different WORLD_SIZE is an error, and without a
+    launcher the script starts the ranks itself (here every rank then stops at "needs an MI355X": there is no CPU path)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"--gpus 2 but the launcher started WORLD_SIZE=3" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert b"spawning 2 ranks" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count(b"needs an MI355X") >= 2
