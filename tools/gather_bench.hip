@@ -1,7 +1,13 @@
 // gather_bench.hip — what random dependent 16-byte gathers cost on this chip (the access pattern of an
 // FM-index step): every lane chases its own pseudo-random chain through a table of 64-byte records.
-//   ./gather_bench <table_MB> <loads_per_step: 1|2|3> <steps> [record_bytes=64]
-// Reports G steps/s and GB/s of touched 64-byte records.  Used to set the practical roofline in DESIGN.md.
+//   ./gather_bench <table_MB> <mode> <steps> [lanes]
+//   mode 1|2|3 : that many loads inside ONE random 64-byte record per step (16 B; 8 B + 16 B; 16 + 16 + 16 B)
+//   mode 4     : two 16-byte loads per step, one in each 64-byte half of ONE random 128-byte aligned line
+//   mode 5     : two 16-byte loads per step in two INDEPENDENT random 64-byte records
+//   mode 6     : one 4-byte load per step (random dword)
+// Reports G steps/s and GB/s of touched 64-byte records.  Used to set the practical roofline in DESIGN.md; modes 1, 4, 5
+// under `rocprofv3 --pmc TCC_EA0_RDREQ_sum FETCH_SIZE` calibrate how many bytes a fabric read request of a random gather
+// carries (tools/gather_calib.sh): the number of records touched is known exactly (lanes x steps).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,11 +31,23 @@ __global__ void chase(const uint64_t *tab, uint64_t nrec, int steps, uint64_t *o
       const uint64_t m = rec[x & 3];
       const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec + 4 + 2 * ((x >> 2) & 1));
       v = m ^ a.x ^ a.y;
-    } else {
+    } else if (LOADS == 3) {
       const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec);
       const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(rec + 2);
       const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(rec + 4 + 2 * ((x >> 2) & 1));
       v = a.x ^ a.y ^ b.x ^ b.y ^ c.x ^ c.y;
+    } else if (LOADS == 4) {      // both halves of one 128-byte line
+      const uint64_t *line = tab + (r & ~1ull) * 8;
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(line + 2 * (x & 3));
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(line + 8 + 2 * ((x >> 2) & 3));
+      v = a.x ^ a.y ^ b.x ^ b.y;
+    } else if (LOADS == 5) {      // two independent records
+      const uint64_t r2 = ((x * 0xD1342543DE82EF95ull) >> 11) % nrec;
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(rec + 2 * (x & 3));
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(tab + r2 * 8 + 2 * ((x >> 2) & 3));
+      v = a.x ^ a.y ^ b.x ^ b.y;
+    } else {                      // one dword
+      v = reinterpret_cast<const uint32_t *>(rec)[x & 15];
     }
     acc += v;
     x = x * 6364136223846793005ull + 1442695040888963407ull + v;   // next address depends on the loaded data
@@ -60,7 +78,10 @@ int main(int argc, char **argv) {
     const unsigned grid = (unsigned)(lanes / 256);
     if (loads == 1) chase<1><<<grid, 256>>>(tab, nrec, steps, out);
     else if (loads == 2) chase<2><<<grid, 256>>>(tab, nrec, steps, out);
-    else chase<3><<<grid, 256>>>(tab, nrec, steps, out);
+    else if (loads == 3) chase<3><<<grid, 256>>>(tab, nrec, steps, out);
+    else if (loads == 4) chase<4><<<grid, 256>>>(tab, nrec, steps, out);
+    else if (loads == 5) chase<5><<<grid, 256>>>(tab, nrec, steps, out);
+    else chase<6><<<grid, 256>>>(tab, nrec, steps, out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms;
