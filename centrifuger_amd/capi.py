@@ -50,6 +50,7 @@ EXPORTS = [
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
     "cfr_device_index_destroy", "cfr_device_index_get_info", "cfr_device_index_set_dust", "cfr_dust_mask_device",
     "cfr_dust_mask_batch_literal",
+    "cfr_selfcheck_tables",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
@@ -235,6 +236,13 @@ class DeviceIndex:
         steps = np.zeros(n, dtype=np.uint32)
         _check(lib().cfr_locate_rows(self._d, _p(rows), C.c_size_t(n), _p(val), _p(steps)))
         return val, steps
+
+    def selfcheck(self):
+        """dict of the derived-table self-check (all bad_* must be 0)"""
+        out = np.zeros(6, dtype=np.uint64)
+        _check(lib().cfr_selfcheck_tables(self._d, _p(out)))
+        return {"bad_sa_isa": int(out[0]), "bad_text": int(out[1]), "bad_lf": int(out[2]), "bad_memo": int(out[3]),
+                "text_tables": bool(out[4]), "memo": int(out[5])}
 
     # ---- the path
     def search(self, bases1, offsets1, bases2=None, offsets2=None):

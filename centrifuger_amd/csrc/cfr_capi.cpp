@@ -126,6 +126,11 @@ cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uin
   return guarded([&]() -> cfr_status { d->d->locate_rows(rows, n, out_val, out_steps); return CFR_OK; });
 }
 
+cfr_status cfr_selfcheck_tables(cfr_dev_index *d, uint64_t out[6]) {
+  if (!d || !out) return bad_arg("cfr_selfcheck_tables: null argument");
+  return guarded([&]() -> cfr_status { d->d->selfcheck(out); return CFR_OK; });
+}
+
 cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
                             const uint64_t *offsets2, size_t n, cfr_hit *out_hits, size_t hit_cap, uint64_t *hit_begin) {
   if (!d || !hit_begin || (n && (!bases1 || !offsets1))) return bad_arg("cfr_search_batch: null argument");

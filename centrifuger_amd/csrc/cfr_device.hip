@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "cfr_tail.hpp"      // dust_mask: the host twin the device SDUST falls back to
 #include "cfr_kernels.hip.inc"
@@ -19,6 +20,14 @@ inline void hip_check(hipError_t e, const char *what) {
   if (e != hipSuccess) throw HipError{std::string(what) + ": " + hipGetErrorString(e), (int)e};
 }
 #define HIP_CHECK(x) hip_check((x), #x)
+
+// The CFR_* switches of DESIGN.md section 5 are A/B and test hooks, not part of the library's interface: they are only
+// looked at when CFR_DEBUG_ENV=1 is set in the environment (one documented gate; a production caller never sets it and
+// the library then has no hidden inputs - everything a caller chooses goes through cfr_device_options).
+inline const char *dbg_env(const char *name) {
+  static const bool on = [] { const char *g = ::getenv("CFR_DEBUG_ENV"); return g && atoi(g) != 0; }();
+  return on ? ::getenv(name) : nullptr;
+}
 
 constexpr int kBlock = 256;
 inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
@@ -85,21 +94,23 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
-  if (const char *e = getenv("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
-  if (const char *e = getenv("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
-  else if (const char *e2 = getenv("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
+  if (const char *e = dbg_env("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
+  if (const char *e = dbg_env("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
+  else if (const char *e2 = dbg_env("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
   if (opt.sub_batch) sub_batch_ = (size_t)opt.sub_batch;
-  if (const char *e = getenv("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
+  if (const char *e = dbg_env("CFR_SUBBATCH")) sub_batch_ = std::max<size_t>(1, strtoull(e, nullptr, 10));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device));
   num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char *e = getenv("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
-  if (const char *e = getenv("CFR_FUSED_TAIL")) fused_tail_ = atoi(e) != 0;
-  if (const char *e = getenv("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
-  if (const char *e = getenv("CFR_TAPER_FLOOR")) taper_floor_ = strtoull(e, nullptr, 10);
+  if (const char *e = dbg_env("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
+  if (const char *e = dbg_env("CFR_FUSED_TAIL")) fused_tail_ = atoi(e) != 0;
+  if (const char *e = dbg_env("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
+  if (const char *e = dbg_env("CFR_TAPER_FLOOR")) taper_floor_ = strtoull(e, nullptr, 10);
+  wide_ = h.n >= 0xfffffff0ull;
+  if (const char *e = dbg_env("CFR_FORCE_WIDE")) wide_ = wide_ || atoi(e) != 0;      // test hook: the n >= 2^32 code path on a small index
 
   // CFR_LOAD_TIMING=1: seconds per load stage on stderr
-  const bool load_timing = getenv("CFR_LOAD_TIMING") && atoi(getenv("CFR_LOAD_TIMING"));
+  const bool load_timing = dbg_env("CFR_LOAD_TIMING") && atoi(dbg_env("CFR_LOAD_TIMING"));
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!load_timing) return;
@@ -112,9 +123,9 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   // CFR_PROFILE=fast-load: skip the large derived tables (a command-line run is bound by FASTQ parsing, not by the device;
   // what it feels is the load time).  Default: throughput (all tables).  The specific switches below override either.
   bool fast_load = opt.profile == CFR_PROFILE_FAST_LOAD;
-  if (const char *e = getenv("CFR_PROFILE")) fast_load = std::string(e) == "fast-load";
+  if (const char *e = dbg_env("CFR_PROFILE")) fast_load = std::string(e) == "fast-load";
   bool layout_rb = opt.run_block_layout != 0;
-  if (const char *e = getenv("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
+  if (const char *e = dbg_env("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
   memset(&view_.rb, 0, sizeof(view_.rb));
   uint64_t *d_occ = nullptr;
   {
@@ -268,7 +279,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
     if (fast_load) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
-    if (const char *e = getenv("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
+    if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
       const uint64_t entries = 1ull << (2 * K);
@@ -282,47 +293,65 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   }
   lap("side tables + ftabx");
   // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
-  view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
+  view_.sa32 = nullptr; view_.isa32 = nullptr; view_.sa40 = nullptr; view_.isa40 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
-    const bool possible = h.n >= 64 && h.n < 0xfffffff0ull && !layout_rb;
+    const bool wide = wide_;                                // rows and text positions no longer fit 32 bits: 5-byte entries
+    const bool possible = h.n >= 64 && h.n < (1ull << 38) && !layout_rb;
     bool want = possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
-    if (const char *e = getenv("CFR_TEXT_MODE")) want = possible && atoi(e) != 0;
+    if (const char *e = dbg_env("CFR_TEXT_MODE")) want = possible && atoi(e) != 0;
+    const size_t esz = wide ? 5 : 4;
+    size_t free_b = 0, total_b = 0;
+    if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)h.n * (2.0 * esz + 0.25) + (double)(h.n >> 3) > 0.9 * (double)free_b) want = false;   // no room
     if (want) try {
-      uint2 *la = nullptr, *lb = nullptr;
-      HIP_CHECK(hipMalloc((void **)&la, h.n * sizeof(uint2)));
-      if (hipMalloc((void **)&lb, h.n * sizeof(uint2)) != hipSuccess) { (void)hipFree(la); throw HipError{"no room for the list-ranking buffers", -3}; }
-      const unsigned g = (unsigned)std::min<uint64_t>((h.n + 255) / 256, 1u << 20);
-      k_lf_init<<<g, 256, 0, stream_>>>(view_, la);
-      for (uint64_t span = 1; span < h.n; span <<= 1) {
-        k_lf_jump<<<g, 256, 0, stream_>>>(h.n, la, lb);
-        std::swap(la, lb);
+      // list ranking by rulers (cfr_kernels.hip.inc): one ruler every 2^kRulerShift rows + the two ends of the list
+      const uint64_t nrulers = ((h.n - 1) >> kRulerShift) + 1, cnt = nrulers + 2;      // + terminal + head of the list
+      uint32_t *nx_a = (uint32_t *)temp_alloc(cnt * 4), *nx_b = (uint32_t *)temp_alloc(cnt * 4);
+      uint64_t *ds_a = (uint64_t *)temp_alloc(cnt * 8), *ds_b = (uint64_t *)temp_alloc(cnt * 8);
+      const unsigned gr = (unsigned)std::min<uint64_t>((cnt + 255) / 256, (uint64_t)num_cus_ * 32);
+      k_ruler_walk<<<gr, 256, 0, stream_>>>(view_, nrulers, nx_a, ds_a);
+      HIP_CHECK(hipGetLastError());
+      for (uint64_t span = 1; span < cnt; span <<= 1) {
+        k_ruler_jump<<<gr, 256, 0, stream_>>>(cnt, nx_a, ds_a, nx_b, ds_b);
+        std::swap(nx_a, nx_b);
+        std::swap(ds_a, ds_b);
       }
       HIP_CHECK(hipGetLastError());
-      uint32_t *d_sa = dev_alloc<uint32_t>(h.n + 8), *d_isa = dev_alloc<uint32_t>(h.n + 8);   // +8: slots are read 16 bytes at a time
+      uint8_t *d_sa = dev_alloc<uint8_t>(h.n * esz + 64), *d_isa = dev_alloc<uint8_t>(h.n * esz + 64);   // + pad: slots are read 16 (32) bytes at a time
       const uint64_t twords = (h.n + 31) / 32 + 4;
       uint64_t *d_text = dev_alloc<uint64_t>(twords) + 1;                                      // one pad word in front (see k_search_chains_v2)
       HIP_CHECK(hipMemsetAsync(d_text - 1, 0, twords * 8, stream_));
-      HIP_CHECK(hipMemsetAsync(d_sa + h.n, 0, 32, stream_));
-      HIP_CHECK(hipMemsetAsync(d_isa + h.n, 0, 32, stream_));
-      k_text_fill<<<g, 256, 0, stream_>>>(view_, la, d_sa, d_isa, (unsigned long long *)d_text);
+      HIP_CHECK(hipMemsetAsync(d_sa + h.n * esz, 0, 64, stream_));
+      HIP_CHECK(hipMemsetAsync(d_isa + h.n * esz, 0, 64, stream_));
+      if (wide) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
+      else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
-      HIP_CHECK(hipFree(la));
-      HIP_CHECK(hipFree(lb));
-      view_.sa32 = d_sa; view_.isa32 = d_isa; view_.text2 = d_text;
+      temp_free(nx_a); temp_free(nx_b); temp_free(ds_a); temp_free(ds_b);
+      if (wide) { view_.sa40 = d_sa; view_.isa40 = d_isa; }
+      else { view_.sa32 = (const uint32_t *)d_sa; view_.isa32 = (const uint32_t *)d_isa; }
+      view_.text2 = d_text;
       uint32_t log4n = 0;
       while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
       view_.text_min_l = log4n + 2;                       // random matches rarely get past log4(n) characters
-      if (const char *e = getenv("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
-    } catch (const HipError &) { (void)hipGetLastError(); view_.sa32 = nullptr; view_.isa32 = nullptr; view_.text2 = nullptr; }   // optional tables
+      if (const char *e = dbg_env("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
+    } catch (const HipError &) {                           // optional tables: run without them (what was allocated stays owned and is freed with the image)
+      (void)hipGetLastError();
+      view_.sa32 = nullptr; view_.isa32 = nullptr; view_.sa40 = nullptr; view_.isa40 = nullptr; view_.text2 = nullptr;
+    }
   }
   lap("SA / ISA / text (list ranking)");
   // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
   view_.loc_memo = nullptr;
   view_.memo_shift = 0;
   {
-    double budget_gb = opt.loc_memo_gb >= 0 ? opt.loc_memo_gb : (fast_load ? 0.0 : 16.0);
-    if (const char *e = getenv("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
+    // default budget: a memo at every row when 60 % of what is still free holds it (4 bytes per row), at least 16 GB worth
+    double budget_gb = opt.loc_memo_gb;
+    if (budget_gb < 0) {
+      budget_gb = fast_load ? 0.0 : 16.0;
+      size_t free_b = 0, total_b = 0;
+      if (!fast_load && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_gb = std::max(budget_gb, 0.6 * (double)free_b / 1e9);
+    }
+    if (const char *e = dbg_env("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;
     for (uint64_t x : h.selected_vals) max_val = std::max(max_val, x);
     const bool fits32 = h.sampled_bits <= 32 && max_val <= 0xffffffffull;
@@ -433,6 +462,21 @@ void DeviceIndex::locate_rows(const uint64_t *rows, size_t n, uint64_t *out_val,
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+void DeviceIndex::selfcheck(uint64_t out[6]) {
+  HIP_CHECK(hipSetDevice(device_));
+  unsigned long long *d_bad = (unsigned long long *)scratch(S_P0, 4 * 8), h_bad[4];
+  HIP_CHECK(hipMemsetAsync(d_bad, 0, 4 * 8, stream_));
+  const unsigned g = (unsigned)std::min<uint64_t>((view_.n + 255) / 256, (uint64_t)num_cus_ * 32);
+  if (wide_) k_selfcheck<true><<<g, 256, 0, stream_>>>(view_, d_bad);
+  else k_selfcheck<false><<<g, 256, 0, stream_>>>(view_, d_bad);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipMemcpyAsync(h_bad, d_bad, 4 * 8, hipMemcpyDeviceToHost, stream_));
+  HIP_CHECK(hipStreamSynchronize(stream_));
+  for (int k = 0; k < 4; ++k) out[k] = h_bad[k];
+  out[4] = (wide_ ? view_.sa40 != nullptr : view_.sa32 != nullptr) ? 1 : 0;      // text-mode tables present
+  out[5] = view_.loc_memo ? 1 + view_.memo_shift : 0;                            // locate memo present (1 + log2 of its row rate)
+}
+
 // ------------------------------------------------------------------------------------ the path
 namespace {
 void exclusive_scan(void *tmp, size_t tmp_bytes, const uint64_t *in, uint64_t *out, size_t count, hipStream_t st) {
@@ -502,8 +546,11 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     int resident = blocks_per_cu_;
     {
       int occ = 0;
-      const hipError_t e = paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<4, false>, kBlock, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<2, false>, kBlock, 0);
+      const bool wide_k = wide_;
+      const hipError_t e = wide_k ? (paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<4, false, true>, kBlock, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<2, false, true>, kBlock, 0))
+                                  : (paired ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<4, false>, kBlock, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<2, false>, kBlock, 0));
       if (e == hipSuccess && occ > 0) resident = std::min(resident, occ);
       else (void)hipGetLastError();
     }
@@ -512,11 +559,12 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.n = view_.n; sv.first_isa = view_.first_isa;
     for (int c = 0; c < 4; ++c) sv.C[c] = view_.C[c];
     sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
-    sv.sa32 = view_.sa32; sv.isa32 = view_.isa32;
+    sv.sa32 = view_.sa32; sv.isa32 = view_.isa32; sv.sa40 = view_.sa40; sv.isa40 = view_.isa40;
+    const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
-    if (getenv("CFR_SEARCH_PROF") && !paired) {
+    if (dbg_env("CFR_SEARCH_PROF") && !paired && !wide) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
       HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * 8, stream_));
@@ -527,6 +575,10 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 11; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
+    } else
+    if (wide) {
+      if (paired) k_search_chains_v2<4, false, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
+      else k_search_chains_v2<2, false, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
     } else
     if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
     else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
@@ -858,7 +910,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       std::vector<size_t> again;
       for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
       todo.swap(again);
-      if (todo.empty() || pool_cap_ >= pool_limit || getenv("CFR_POOL_CAP")) break;
+      if (todo.empty() || pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP")) break;
       pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it
     }
   }
@@ -900,7 +952,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
 void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,
                                 cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent) {
   HIP_CHECK(hipSetDevice(device_));
-  static const bool stream_inputs = !(getenv("CFR_STREAM_INPUTS") && atoi(getenv("CFR_STREAM_INPUTS")) == 0);
+  static const bool stream_inputs = !(dbg_env("CFR_STREAM_INPUTS") && atoi(dbg_env("CFR_STREAM_INPUTS")) == 0);
   if (n && stream_inputs && !search_v1_ && view_.max_result > 0 && one_launch_ready()) {
     // streamed form: only the offsets go up front; the bases of sub-batch k+1 are copied (h2d stream) while sub-batch k computes
     const HostSrc src{b1, o1, b2, o2};

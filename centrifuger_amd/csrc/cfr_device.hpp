@@ -13,8 +13,8 @@
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
-//   sa32/isa32/text2 : DERIVED at load time (list ranking over the LF permutation, k_lf_init/k_lf_jump/k_text_fill):
-//              SA[row], ISA[pos] and the 2-bit text.  A BWT range of <= 4 rows is then extended by comparing the read
+//   sa/isa/text2 : DERIVED at load time (list ranking over the LF permutation by rulers, k_ruler_walk/_jump/_fill):
+//              SA[row], ISA[pos] (u32 entries for n < 2^32, 5-byte entries above) and the 2-bit text.  A BWT range of <= 4 rows is then extended by comparing the read
 //              with the text 32 bases per step (the rows' suffix positions move in lock step), instead of one LF
 //              step per base; the range is mapped back with ISA when the search ends.
 //   loc_memo : DERIVED at load time: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
@@ -59,8 +59,10 @@ struct DevView {            // passed by value to kernels
   const uint64_t *sampled;
   const uint32_t *loc_memo; // derived: memo[j / memo_rate] = BackwardToSampledSA(j) for j % memo_rate == 0; nullptr = off
   uint32_t memo_shift;      // log2(memo_rate)
-  // derived text-mode tables (n < 2^32): suffix array, its inverse, and the 2-bit text; nullptr = off
+  // derived text-mode tables: suffix array, its inverse (u32 entries when n < 2^32, 5-byte entries otherwise), and the
+  // 2-bit text; nullptr = off
   const uint32_t *sa32, *isa32;
+  const uint8_t *sa40, *isa40;
   const uint64_t *text2;    // symbol p at bits 2(p%32) of word p/32
   uint32_t text_min_l;      // a search switches to text comparison once it has matched this many characters
   const uint64_t *sel_rows, *sel_vals;
@@ -104,6 +106,9 @@ class DeviceIndex {
   void backward_search_batch(const uint8_t *bases, const uint64_t *offsets, const uint32_t *m, size_t n,
                              uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep);
   void locate_rows(const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps);
+
+  // consistency of the derived tables (SA / ISA / text / locate memo) against the BWT itself; see k_selfcheck
+  void selfcheck(uint64_t out[6]);
 
   // Runs search (+adjust, strand choice) for a batch whose reads are in device memory.
   // On return the per-read final hits are in host vectors (compacted), plus located seqIds per hit if want_rows.
@@ -182,6 +187,7 @@ class DeviceIndex {
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false;
+  bool wide_ = false;                  // n >= 2^32: 5-byte SA / ISA entries and the WIDE search kernel
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;

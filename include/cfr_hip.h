@@ -147,6 +147,12 @@ cfr_status cfr_backward_search_batch(cfr_dev_index *d, const uint8_t *bases, con
 /* FMIndex::BackwardToSampledSA(row): value (a sequence id) and LF-step count */
 cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps);
 
+/* Self-check of the tables the device image derives at load time, against the BWT itself (no reference counterpart: the
+ * reference has no derived tables).  out[0..3] = number of rows where SA/ISA, the 2-bit text, the LF order of SA, the locate
+ * memo (every 61st row, against the plain FMIndex::BackwardToSampledSA walk) disagree - all 0 on a sound image;
+ * out[4] = 1 if the text-mode tables exist, out[5] = 0 without a locate memo, else 1 + log2 of its row rate. */
+cfr_status cfr_selfcheck_tables(cfr_dev_index *d, uint64_t out[6]);
+
 /* ---- the path ---- */
 /* SearchForwardAndReverse for n reads (mates optional: bases2/offsets2 == NULL for single-end).
  * hits of read i are out_hits[hit_begin[i] .. hit_begin[i+1]) ; hit_begin has n+1 entries.

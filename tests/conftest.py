@@ -4,6 +4,8 @@ import sys
 
 import pytest
 
+# the library looks at its CFR_* A/B switches only behind this gate (csrc/cfr_device.hip dbg_env); the variant tests use them
+os.environ.setdefault("CFR_DEBUG_ENV", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")

@@ -73,6 +73,8 @@ def test_permutation_cut_and_determinism_single_end(world):
     k = 3
     rs = world["reads"]
     idx, dev = _open(world["prefix"], k)
+    chk = dev.selfcheck()                   # SA / ISA / text / locate memo of the 100 Mbp image against its BWT, every row
+    assert chk["text_tables"] and chk["memo"] == 1 and (chk["bad_sa_isa"], chk["bad_text"], chk["bad_lf"], chk["bad_memo"]) == (0, 0, 0, 0), chk
     res, mat = dev.classify(rs.bases, rs.offsets)
     sc, slots = canon(res, mat, k)
     assert (res["n_match"] > 0).mean() > 0.99

@@ -26,15 +26,18 @@ VARIANTS = {
     "wide_ftabx_one_block_per_cu": {"CFR_FTABX_WIDTH": "12", "CFR_BLOCKS_PER_CU": "1"},
     # the reference's own compressed components in HBM (rank lines, wavelet trees, run-block rank): whole parity file
     "run_block_layout": {"CFR_LAYOUT": "rb"},
+    # the n >= 2^32 code path (5-byte SA / ISA entries, WIDE search kernel) forced on the small indexes
+    "wide_tables": {"CFR_FORCE_WIDE": "1"},
+    "wide_tables_text_mode_early": {"CFR_FORCE_WIDE": "1", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
 
 @pytest.mark.parametrize("name", sorted(VARIANTS))
 def test_parity_suite_under_switches(name):
-    env = dict(os.environ)
+    env = dict(os.environ, CFR_DEBUG_ENV="1")     # the gate that makes the library look at its CFR_* test switches at all
     env.update(VARIANTS[name])
-    select = [] if name.startswith("run_block") else ["-k", "tsv or hit_lists or backward_search or degenerate or fresh_index"]
+    select = [] if name.startswith("run_block") else ["-k", "tsv or hit_lists or backward_search or degenerate or fresh_index or derived_tables"]
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q"] + select,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
     tail = r.stdout.decode()[-1500:]

@@ -1,4 +1,5 @@
 #!/bin/bash
+export CFR_DEBUG_ENV=1   # the gate behind which the library reads its CFR_* A/B switches
 # Stage timing of the drop-in command line on the bench sample (run on the GPU box after bench.py has filled its cache).
 mkdir -p gpurun_out
 python bench.py --steps 2 --warmup 1 > gpurun_out/cli_bench.json 2> gpurun_out/cli_bench.err

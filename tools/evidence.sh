@@ -1,4 +1,5 @@
 #!/bin/bash
+export CFR_DEBUG_ENV=1   # the gate behind which the library reads its CFR_* A/B switches
 # One evidence pass on the GPU box: bench lines (SE with the CPU baseline + parity, PE, long), the kernel trace of the
 # default bench command, and the PMC passes.  usage: tools/evidence.sh <tag>     -> gpurun_out/<tag>_*
 set -u

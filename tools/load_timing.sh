@@ -1,4 +1,5 @@
 #!/bin/bash
+export CFR_DEBUG_ENV=1   # the gate behind which the library reads its CFR_* A/B switches
 # Load-stage timing of the device index on the bench index (GPU box).
 mkdir -p gpurun_out
 python bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
