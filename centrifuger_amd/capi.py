@@ -50,7 +50,7 @@ EXPORTS = [
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
     "cfr_device_index_destroy", "cfr_device_index_get_info", "cfr_device_index_set_dust", "cfr_dust_mask_device",
     "cfr_dust_mask_batch_literal",
-    "cfr_selfcheck_tables",
+    "cfr_selfcheck_tables", "cfr_build_index", "cfr_build_options_default",
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
@@ -74,7 +74,7 @@ def lib():
         L.cfr_host_free.argtypes = [C.c_void_p]
         for name in EXPORTS:
             if name not in ("cfr_last_error", "cfr_version", "cfr_tsv_header", "cfr_format_tsv", "cfr_index_destroy",
-                            "cfr_device_index_destroy", "cfr_params_default", "cfr_host_alloc", "cfr_host_free"):
+                            "cfr_device_index_destroy", "cfr_params_default", "cfr_host_alloc", "cfr_host_free", "cfr_build_options_default"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -103,6 +103,55 @@ def _u8(a):
 
 def _u64(a):
     return None if a is None else np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class BuildInput(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint64), ("seq_names", C.POINTER(C.c_char_p)), ("seq_taxids", C.c_void_p), ("seq_lens", C.c_void_p),
+                ("text", C.c_void_p), ("n_nodes", C.c_uint64), ("node_taxid", C.c_void_p), ("node_parent", C.c_void_p),
+                ("node_rank", C.POINTER(C.c_char_p)), ("n_names", C.c_uint64), ("name_taxid", C.c_void_p), ("name_text", C.POINTER(C.c_char_p))]
+
+
+class BuildOptions(C.Structure):
+    _fields_ = [("ftab_chars", C.c_int32), ("offrate", C.c_int32), ("device", C.c_int32), ("threads", C.c_int32), ("rbbwt_b", C.c_uint64),
+                ("verbose", C.c_int32), ("reserved", C.c_int32)]
+
+
+class BuildReport(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("block_size", C.c_uint64), ("first_isa", C.c_uint64), ("seconds_sa", C.c_double),
+                ("seconds_total", C.c_double), ("rounds", C.c_int32), ("pad", C.c_int32)]
+
+
+def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10, offrate=4, rbbwt_b=0, device=0, threads=0, verbose=False):
+    """cfr_build_index: the native writer (suffix array on the MI355X).  seqs: list of np.uint8 ASCII arrays, or one
+    concatenated array together with `names`-many lengths given as (text, lens)."""
+    if isinstance(seqs, tuple):
+        text, lens = seqs
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    else:
+        lens = np.array([len(x) for x in seqs], dtype=np.uint64)
+        text = np.ascontiguousarray(np.concatenate(seqs), dtype=np.uint8)
+
+    def strs(items):
+        arr = (C.c_char_p * len(items))()
+        arr[:] = [x.encode() if isinstance(x, str) else x for x in items]
+        return arr
+    inp = BuildInput()
+    keep = [strs(list(names)), _u64(np.array(taxids, dtype=np.uint64)), lens, text,
+            _u64(np.array([t for t, _, _ in nodes], dtype=np.uint64)), _u64(np.array([p for _, p, _ in nodes], dtype=np.uint64)),
+            strs([r for _, _, r in nodes]), _u64(np.array([t for t, _ in tax_names], dtype=np.uint64)), strs([x for _, x in tax_names])]
+    inp.n_seqs = len(names)
+    inp.seq_names = keep[0]
+    inp.seq_taxids = _p(keep[1]); inp.seq_lens = _p(keep[2]); inp.text = _p(keep[3])
+    inp.n_nodes = len(nodes); inp.node_taxid = _p(keep[4]); inp.node_parent = _p(keep[5]); inp.node_rank = keep[6]
+    inp.n_names = len(tax_names); inp.name_taxid = _p(keep[7]); inp.name_text = keep[8]
+    opt = BuildOptions()
+    lib().cfr_build_options_default(C.byref(opt))
+    opt.ftab_chars, opt.offrate, opt.device, opt.threads, opt.rbbwt_b, opt.verbose = ftab_chars, offrate, device, threads, rbbwt_b, int(verbose)
+    rep = BuildReport()
+    _check(lib().cfr_build_index(C.byref(inp), C.byref(opt), out_prefix.encode(), C.byref(rep)))
+    return {"n": rep.n, "b": rep.block_size, "first_isa": rep.first_isa, "seconds_sa": rep.seconds_sa, "seconds_total": rep.seconds_total,
+            "rounds": rep.rounds}
 
 
 class Index:

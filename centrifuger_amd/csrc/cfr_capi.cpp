@@ -4,6 +4,7 @@
 #include <string>
 #include <thread>
 
+#include "cfr_build.hpp"
 #include "cfr_device.hpp"
 #include "cfr_tail.hpp"
 
@@ -124,6 +125,38 @@ cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uin
   if (!d || (n && (!rows || !out_val))) return bad_arg("cfr_locate_rows: null argument");
   for (size_t i = 0; i < n; ++i) if (rows[i] >= d->d->host().n) return bad_arg("cfr_locate_rows: row out of range");
   return guarded([&]() -> cfr_status { d->d->locate_rows(rows, n, out_val, out_steps); return CFR_OK; });
+}
+
+void cfr_build_options_default(cfr_build_options *o) {
+  if (!o) return;
+  memset(o, 0, sizeof(*o));
+  o->ftab_chars = 10; o->offrate = 4;
+}
+cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *opt, const char *out_prefix, cfr_build_report *report) {
+  if (!in || !out_prefix) return bad_arg("cfr_build_index: null argument");
+  if (!in->n_seqs || !in->seq_names || !in->seq_taxids || !in->seq_lens || !in->text) return bad_arg("cfr_build_index: empty input");
+  if ((in->n_nodes && (!in->node_taxid || !in->node_parent || !in->node_rank)) || (in->n_names && (!in->name_taxid || !in->name_text)))
+    return bad_arg("cfr_build_index: taxonomy arrays missing");
+  return guarded([&]() -> cfr_status {
+    cfr::BuildInput bi;
+    for (uint64_t i = 0; i < in->n_seqs; ++i) {
+      bi.names.emplace_back(in->seq_names[i]);
+      bi.taxids.push_back(in->seq_taxids[i]);
+      bi.lens.push_back(in->seq_lens[i]);
+    }
+    bi.text = in->text;
+    for (uint64_t i = 0; i < in->n_nodes; ++i) bi.nodes.push_back(cfr::TaxNode{in->node_taxid[i], in->node_parent[i], in->node_rank[i] ? in->node_rank[i] : ""});
+    for (uint64_t i = 0; i < in->n_names; ++i) bi.tax_names.emplace_back(in->name_taxid[i], in->name_text[i] ? in->name_text[i] : "");
+    cfr::BuildOptions bo;
+    if (opt) { bo.ftab_chars = opt->ftab_chars; bo.offrate = opt->offrate; bo.device = opt->device; bo.threads = opt->threads; bo.rbbwt_b = opt->rbbwt_b; bo.verbose = opt->verbose != 0; }
+    cfr::BuildReport rep;
+    cfr::build_index_files(bi, bo, out_prefix, &rep);
+    if (report) {
+      report->n = rep.n; report->block_size = rep.block_size; report->first_isa = rep.first_isa;
+      report->seconds_sa = rep.seconds_sa; report->seconds_total = rep.seconds_total; report->rounds = rep.rounds; report->pad = 0;
+    }
+    return CFR_OK;
+  });
 }
 
 cfr_status cfr_selfcheck_tables(cfr_dev_index *d, uint64_t out[6]) {

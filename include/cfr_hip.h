@@ -212,6 +212,40 @@ size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_resul
                       char *buf, size_t cap);
 const char *cfr_tsv_header(void);
 
+/* ---- index writer (outside the classification path) ----
+ * What `centrifuger-build` produces (Builder::Build + FMBuilder, Builder.hpp:86-313, compactds/FMBuilder.hpp:209-313):
+ * <out_prefix>.{1,2,3,4}.cfr for nucleotide sequences, default layout options (--rbbwt-b / --offrate / --ftabchars
+ * honoured).  The suffix array is built in the HBM of one MI355X (texts below 2^34 symbols); there is no CPU path.
+ * bin/centrifuger-build is the command line on top of it. */
+typedef struct {
+  uint64_t n_seqs;
+  const char *const *seq_names;     /* conversion-table order = sequence ids */
+  const uint64_t *seq_taxids;       /* original tax id of every sequence */
+  const uint64_t *seq_lens;         /* length of every sequence */
+  const uint8_t *text;              /* the sequences back to back: upper-case A,C,G,T only (SequenceCompactor.hpp:59-84 drops the rest) */
+  uint64_t n_nodes;                 /* nodes.dmp */
+  const uint64_t *node_taxid, *node_parent;
+  const char *const *node_rank;
+  uint64_t n_names;                 /* names.dmp, scientific names */
+  const uint64_t *name_taxid;
+  const char *const *name_text;
+} cfr_build_input;
+typedef struct {
+  int32_t ftab_chars;   /* --ftabchars, default 10 */
+  int32_t offrate;      /* --offrate, default 4: SA sampled every 2^offrate rows */
+  int32_t device;       /* HIP device ordinal */
+  int32_t threads;      /* host threads of the compression / writing half, 0 = automatic */
+  uint64_t rbbwt_b;     /* --rbbwt-b, 0 = automatic block size */
+  int32_t verbose, reserved;
+} cfr_build_options;
+typedef struct {
+  uint64_t n, block_size, first_isa;
+  double seconds_sa, seconds_total;
+  int32_t rounds, pad;
+} cfr_build_report;
+void cfr_build_options_default(cfr_build_options *o);
+cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *opt, const char *out_prefix, cfr_build_report *report);
+
 #ifdef __cplusplus
 }
 #endif

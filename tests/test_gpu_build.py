@@ -1,0 +1,95 @@
+"""The native index writer (cfr_build_index: suffix array in HBM, csrc/cfr_build_sa.hip + cfr_build.cpp) against the indexes
+the REAL reference's centrifuger-build wrote for the same genomes (tests/golden/*.cfr), against the Python restatement of
+the writer (centrifuger_amd/indexbuild.py, CPU torch), and against a suffix array sorted naively.  -m gpu."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from centrifuger_amd import capi, synth
+from cfr_fields import parse_1cfr
+from conftest import GOLDEN, REF_DIR, have_ref
+
+pytestmark = pytest.mark.gpu
+MAN = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+VARIANTS = {"f6": dict(ftab_chars=6), "f6_b1": dict(ftab_chars=6, rbbwt_b=1), "f6_b8": dict(ftab_chars=6, rbbwt_b=8),
+            "f6_off3": dict(ftab_chars=6, offrate=3), "f10": dict()}
+
+
+@pytest.fixture(scope="module")
+def genomes():
+    return synth.make_genomes(n_species=5, n_strains=3, genome_len=20000, seed=MAN["seed"])
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_native_writer_equals_reference_index_field_by_field(name, genomes, golden_dir, tmp_path):
+    g = genomes
+    prefix = str(tmp_path / name)
+    rep = capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, **VARIANTS[name])
+    assert rep["n"] == g.total_len
+    mine = parse_1cfr(prefix + ".1.cfr")
+    ref = parse_1cfr(os.path.join(golden_dir, name + ".1.cfr"))
+    assert len(mine) == len(ref)
+    for (na, va), (nb, vb) in zip(mine, ref):
+        assert na == nb
+        assert va == vb, f"field {na} differs"
+    assert open(prefix + ".2.cfr", "rb").read() == open(os.path.join(golden_dir, name + ".2.cfr"), "rb").read()
+
+
+def _naive_bwt(t):
+    s = bytes(t.tolist())
+    sa = sorted(range(len(s)), key=lambda i: s[i:])
+    return sa
+
+
+@pytest.mark.parametrize("kind", ["random", "long_repeat", "homopolymer_tail", "duplicate_genome", "periodic"])
+def test_suffix_order_on_adversarial_texts(kind, tmp_path):
+    """Texts that stress the doubling rounds and the end-of-text rule (a proper prefix sorts first): the written BWT /
+    firstISA must be those of the naively sorted suffixes."""
+    rng = np.random.default_rng(7)
+    n = 5000
+    t = rng.integers(0, 4, size=n, dtype=np.uint8)
+    if kind == "long_repeat":
+        t[1000:3000] = t[3000:5000]
+    elif kind == "homopolymer_tail":
+        t[-700:] = 0                      # ...AAAA at the very end: every suffix of the tail is a prefix of the previous one
+        t[2000:2600] = 0
+    elif kind == "duplicate_genome":
+        t[2500:] = t[:2500]
+    elif kind == "periodic":
+        t[:] = np.tile(np.array([0, 1, 0, 1, 1, 3], dtype=np.uint8), n // 6 + 1)[:n]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [acgt[t[:n // 2]], acgt[t[n // 2:]]]
+    g = synth.Genomes(["a", "b"], [1000, 1001], seqs, [(1, 1, "no rank"), (1000, 1, "species"), (1001, 1, "species")], [(1, "root"), (1000, "x"), (1001, "y")])
+    prefix = str(tmp_path / kind)
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=4, rbbwt_b=1)
+    sa = _naive_bwt(t)
+    want_first_isa = sa.index(0)
+    want_bwt = [int(t[p - 1]) if p else int(t[n - 1]) for p in sa]
+    idx = capi.Index(prefix)
+    assert idx.info().first_isa == want_first_isa
+    dev = capi.DeviceIndex(idx)
+    _, acc = dev.rank(np.full(n, ord("A"), dtype=np.uint8), np.arange(n, dtype=np.uint64), np.ones(n, dtype=np.uint8))
+    assert bytes(acc) == bytes(acgt[np.array(want_bwt)])
+    assert dev.selfcheck()["bad_sa_isa"] == 0
+    dev.close()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
+def test_native_writer_equals_reference_builder_on_a_fresh_3mbp_text(tmp_path):
+    """centrifuger-build of the reference and the native writer on the same 3 Mbp input: .1.cfr fields and .2.cfr bytes equal."""
+    g = synth.make_genomes(n_species=6, n_strains=4, genome_len=125000, seed=91)
+    synth.write_reference_inputs(g, str(tmp_path))
+    ref_prefix = str(tmp_path / "ref")
+    subprocess.run([os.path.join(REF_DIR, "centrifuger-build"), "-t", "8", "-r", str(tmp_path / "ref.fa"), "--taxonomy-tree", str(tmp_path / "nodes.dmp"),
+                    "--name-table", str(tmp_path / "names.dmp"), "--conversion-table", str(tmp_path / "seqid.map"), "-o", ref_prefix],
+                   check=True, stderr=subprocess.DEVNULL)
+    prefix = str(tmp_path / "own")
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
+    mine, ref = parse_1cfr(prefix + ".1.cfr"), parse_1cfr(ref_prefix + ".1.cfr")
+    assert len(mine) == len(ref)
+    for (na, va), (nb, vb) in zip(mine, ref):
+        assert na == nb and va == vb, f"field {na} differs"
+    assert open(prefix + ".2.cfr", "rb").read() == open(ref_prefix + ".2.cfr", "rb").read()
