@@ -37,21 +37,34 @@ def log(*a):
 
 
 def build_index(args, cache, device=None):
-    """Index generation is OUT of the timed path.  --builder own: centrifuger_amd/indexbuild.py (suffix array by
-    prefix doubling with torch sorts in HBM, writes the same .cfr fields as the reference's builder, see
-    tests/test_indexbuild.py); --builder reference: the reference's own centrifuger-build (oracle/_ref)."""
+    """Index generation is OUT of the timed path.  --builder own: the native writer behind cfr_build_index (suffix array in
+    HBM, csrc/cfr_build_sa.hip; writes the same .cfr fields as the reference's builder, tests/test_gpu_build.py);
+    --builder reference: the reference's own centrifuger-build (oracle/_ref); --builder python: centrifuger_amd/indexbuild.py
+    (the torch restatement of the writer, texts below 2.1 Gbp)."""
     from centrifuger_amd import synth
     prefix = os.path.join(cache, "idx")
     if os.path.exists(prefix + ".done"):
         return prefix
     os.makedirs(cache, exist_ok=True)
     t0 = time.time()
-    g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step)
-    np.save(os.path.join(cache, "genome_cat.npy"), np.concatenate(g.seqs))
-    np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum([len(s) for s in g.seqs])]).astype(np.int64))
+    if args.index_gbp:      # multi-Gbp texts: threaded generator, one buffer (not the random stream of the cfg2 text)
+        g, cat = synth.make_genomes_fast(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step,
+                                         threads=min(os.cpu_count() or 1, 64))
+    else:
+        g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step)
+        cat = np.concatenate(g.seqs)
+    np.save(os.path.join(cache, "genome_cat.npy"), cat)
+    lens = np.array([len(s) for s in g.seqs], dtype=np.uint64)
+    np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
     log(f"genomes: {g.total_len/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
     t0 = time.time()
     if args.builder == "own":
+        from centrifuger_amd import capi
+        rep = capi.build_index(g.names, g.taxids, (cat, lens), g.nodes, g.tax_names, prefix, device=device.index or 0 if device is not None else 0, verbose=True)
+        log(f"index built by the native writer (cfr_build_index) in {time.time()-t0:.1f}s: suffix array {rep['seconds_sa']:.1f}s, {rep['rounds']} doubling rounds, b = {rep['b']}")
+        json.dump({"builder": "cfr_build_index", "n": rep["n"], "seconds_total": rep["seconds_total"], "seconds_sa": rep["seconds_sa"],
+                   "rounds": rep["rounds"], "block_size": rep["b"]}, open(prefix + ".build.json", "w"))
+    elif args.builder == "python":
         from centrifuger_amd import indexbuild
         indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=device, log=log)
         log(f"index built by centrifuger_amd.indexbuild in {time.time()-t0:.1f}s")
@@ -235,13 +248,17 @@ def main():
     ap.add_argument("--count-sample", type=int, default=200_000, help="reads the C oracle counts operations on")
     ap.add_argument("--build-threads", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--builder", choices=["own", "reference"], default="own", help="who writes the .cfr index (outside the timed path)")
+    ap.add_argument("--builder", choices=["own", "reference", "python"], default="own", help="who writes the .cfr index (outside the timed path)")
+    ap.add_argument("--index-gbp", type=float, default=0.0, help="size of the synthetic index in Gbp (sets --species; same 5-strain model); "
+                                                                  "0 = BASELINE configs[1] (1 Gbp, the metric's config)")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
     ap.add_argument("--mode", choices=["se", "pe", "long"], default="se",
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
                          "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")
     ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
     args = ap.parse_args()
+    if args.index_gbp:
+        args.species = max(1, int(round(args.index_gbp * 1e9 / (args.strains * args.genome_len))))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly the way the driver does
@@ -279,7 +296,8 @@ def main():
     all_cpus = os.sched_getaffinity(0)
     numa = bind_to_gpu_numa_node(torch, local_rank)      # host threads + pinned buffers next to this rank's GPU
     from centrifuger_amd import capi
-    key = hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")).encode()).hexdigest()[:10]
+    key = hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")
+                       + ("-fastgen" if args.index_gbp else "")).encode()).hexdigest()[:10]
     cache = os.path.join(args.cache, key)
     if rank == 0:
         prefix = build_index(args, cache, device)

@@ -69,6 +69,52 @@ def make_genomes(n_species: int, n_strains: int, genome_len: int, seed: int,
     return Genomes(names, taxids, seqs, nodes, tax_names)
 
 
+def make_genomes_fast(n_species: int, n_strains: int, genome_len: int, seed: int, divergence_step: float = 0.01,
+                       species_per_genus: int = 2, threads: int = 32):
+    """The same genome model as make_genomes for multi-Gbp texts: one generator per species (seed + species number) so that
+    species can be produced by a thread pool, and the sequences land in ONE preallocated buffer.  Returns (Genomes with
+    `seqs` = views into that buffer, the buffer itself).  Not bit-compatible with make_genomes (different random streams)."""
+    from concurrent.futures import ThreadPoolExecutor
+    names, taxids = [], []
+    nodes = [(1, 1, "no rank"), (2, 1, "superkingdom")]
+    tax_names = [(1, "root"), (2, "Bacteria")]
+    next_tid = 1000
+    genus_tid = None
+    for sp in range(n_species):
+        if sp % species_per_genus == 0:
+            genus_tid = next_tid
+            next_tid += 1
+            nodes.append((genus_tid, 2, "genus"))
+            tax_names.append((genus_tid, f"Genus{sp // species_per_genus}"))
+        sp_tid = next_tid
+        next_tid += 1
+        nodes.append((sp_tid, genus_tid, "species"))
+        tax_names.append((sp_tid, f"Genus{sp // species_per_genus} species{sp}"))
+        for k in range(n_strains):
+            nodes.append((next_tid, sp_tid, "strain"))
+            tax_names.append((next_tid, f"species{sp} strain{k}"))
+            names.append(f"SEQ_{sp:04d}_{k}.1")
+            taxids.append(next_tid)
+            next_tid += 1
+    text = np.empty(n_species * n_strains * genome_len, dtype=np.uint8)
+
+    def one(sp):
+        rng = np.random.default_rng([seed, sp])
+        base = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+        for k in range(n_strains):
+            g = base.copy() if k else base
+            if k > 0:
+                nmut = int(genome_len * divergence_step * k)
+                pos = rng.integers(0, genome_len, size=nmut)
+                g[pos] = (g[pos] + rng.integers(1, 4, size=nmut, dtype=np.uint8)) & 3
+            lo = (sp * n_strains + k) * genome_len
+            np.take(ACGT, g, out=text[lo:lo + genome_len])
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(one, range(n_species)))
+    seqs = [text[i * genome_len:(i + 1) * genome_len] for i in range(n_species * n_strains)]
+    return Genomes(names, taxids, seqs, nodes, tax_names), text
+
+
 def write_reference_inputs(g: Genomes, outdir: str, line_width: int = 80):
     """ref.fa + nodes.dmp + names.dmp + seqid.map (inputs of centrifuger-build)."""
     os.makedirs(outdir, exist_ok=True)
@@ -141,10 +187,15 @@ def _concat(g: Genomes):
 
 
 def make_reads(g: Genomes, n_reads: int, read_len: int, seed: int,
-               sub_rate: float = 0.01, n_rate: float = 0.001, chunk: int = 1 << 20) -> ReadSet:
-    """Fixed-length single-end reads, uniform over genomes / positions / strands."""
+               sub_rate: float = 0.01, n_rate: float = 0.001, chunk: int = 1 << 20, cat=None) -> ReadSet:
+    """Fixed-length single-end reads, uniform over genomes / positions / strands.  cat: the genomes back to back, if the
+    caller already holds them in one buffer (make_genomes_fast)."""
     rng = np.random.default_rng(seed)
-    cat, starts = _concat(g)
+    if cat is None:
+        cat, starts = _concat(g)
+    else:
+        starts = np.zeros(len(g.seqs) + 1, dtype=np.int64)
+        starts[1:] = np.cumsum([len(s) for s in g.seqs])
     lens = np.diff(starts)
     out = np.empty((n_reads, read_len), dtype=np.uint8)
     ar = np.arange(read_len, dtype=np.int64)
