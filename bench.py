@@ -232,6 +232,126 @@ def make_long_reads_gpu(torch, cat_d, starts, n_reads, seed, device, len_lo=5000
     return bases, offs
 
 
+BYTES_PER_RANDOM_REQUEST = 128.0     # profiles/r2a_gather_calib.json
+
+
+def kernel_source_sha():
+    h = hashlib.sha1()
+    for f in ("cfr_kernels.hip.inc", "cfr_device.hip", "cfr_device.hpp"):
+        h.update(open(os.path.join(ROOT, "centrifuger_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def live_pmc(args, cache):
+    """HBM-side counters of k_search_chains_v2 measured in THIS run: the bench re-executes itself (--inner: warm-up + one
+    2 M-read step, a single launch) under `rocprofv3 --pmc ... --kernel-trace` - one pass per counter group, as the guide
+    prescribes - plus one un-profiled pass with the kernel's diagnostic instantiation for its iteration mix.
+    Returns None when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if args.mode != "se":
+        return None
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    n_inner = min(2_000_000, args.reads)
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--reads", str(n_inner), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--species", str(args.species), "--strains", str(args.strains), "--genome-len", str(args.genome_len), "--divergence-step", str(args.divergence_step),
+             "--read-len", str(args.read_len), "--seed", str(args.seed), "--builder", args.builder, "--cache", args.cache] + (["--index-gbp", str(args.index_gbp)] if args.index_gbp else [])
+    env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n_inner), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")
+    vals, dur = {}, None
+    work = tempfile.mkdtemp(prefix="cfr_pmc_", dir="/tmp")
+    try:
+        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE"])):
+            d = os.path.join(work, f"pass{gi}")
+            r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "k_search_chains_v2",
+                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                log("live PMC pass failed:", r.stderr.decode()[-400:])
+                return None
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_search_chains_v2" in row["Kernel_Name"]:
+                        vals[row["Counter_Name"]] = float(row["Counter_Value"])          # last dispatch = the timed step
+                        dur = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        if "TCC_EA0_RDREQ_sum" not in vals or "WRITE_SIZE" not in vals:
+            return None
+        prof = None
+        r = subprocess.run(inner, cwd="/tmp", env=dict(env, CFR_SEARCH_PROF="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        for line in r.stderr.decode().splitlines():
+            if line.startswith("[search prof]"):
+                tok = line.split(":", 1)[1].replace("(per read)", "").split()
+                prof = {tok[i]: float(tok[i + 1]) for i in range(0, len(tok) - 1, 2)}      # last launch wins
+        return {"source": f"live in this run: rocprofv3 --pmc (2 passes) around one {n_inner}-read launch of the same build, scaled per read",
+                "reads": n_inner, "rdreq": vals["TCC_EA0_RDREQ_sum"], "rdreq_32b": vals.get("TCC_EA0_RDREQ_32B_sum", 0.0),
+                "fetch_size_kib": vals.get("FETCH_SIZE", 0.0), "write_size_kib": vals["WRITE_SIZE"], "kernel_ms_profiled": dur, "prof": prof,
+                "kernel_source_sha": kernel_source_sha()}
+    except Exception as e:
+        log("live PMC unavailable:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
+    """One of the other BASELINE configs on the same index: timed steps with resident inputs + a check against the C oracle."""
+    paired = mode == "pe"
+    k = 5 if paired else 1
+    n = args.reads if paired else 200_000
+    idx = capi.Index(prefix, capi.default_params(max_result=k))
+    dev = capi.DeviceIndex(idx, device.index or 0)
+    cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
+    starts = np.load(os.path.join(cache, "genome_starts.npy"))
+    cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
+    if paired:
+        r1, r2 = make_pairs_gpu(torch, cat_d, starts, n, args.read_len, args.seed + 2000, device)
+        offs_d = torch.arange(n + 1, device=device, dtype=torch.int64) * args.read_len
+    else:
+        r1, offs_d = make_long_reads_gpu(torch, cat_d, starts, n, args.seed + 3000, device)
+        r2 = None
+    del cat_d
+    torch.cuda.synchronize()
+    offs_h = offs_d.cpu().numpy().astype(np.uint64)
+    total = int(offs_h[-1])
+    res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
+    mat_pin = capi.PinnedArray(n * k, capi.MATCH_DTYPE)
+
+    def step():
+        if paired:
+            return dev.classify_resident(r1.data_ptr(), offs_d.data_ptr(), n, total, r2.data_ptr(), offs_d.data_ptr(), total, results=res_pin.array, matches=mat_pin.array)
+        return dev.classify_resident(r1.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = 3
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = dev.last_stats()
+    # the first reads against the C oracle (score / second score / hit length / match count of every read)
+    nchk = 20_000 if paired else 500
+    hi = int(offs_h[nchk])
+    b1 = r1.reshape(-1)[:hi].cpu().numpy()
+    b2 = r2.reshape(-1)[:hi].cpu().numpy() if paired else None
+    oo = ora.OracleIndex(prefix, max_result=k)
+    ores = oo.classify(b1, offs_h[:nchk + 1].copy(), b2, offs_h[:nchk + 1].copy() if paired else None, dust=False, threads=min(os.cpu_count() or 1, 64))
+    res = res_pin.array
+    same = all((int(res[i]["score"]), int(res[i]["secondary_score"]), int(res[i]["hit_length"]), int(res[i]["n_match"])) ==
+               (ores[i].score, ores[i].secondaryScore, ores[i].hitLength, ores[i].nmatch) for i in range(nchk))
+    out = {"value": n * steps / el, "unit": "read pairs/s" if paired else "reads/s", "ms_per_step": 1000 * el / steps, "steps": steps,
+           "workload": (f"{n} x 2x{args.read_len} bp pairs, insert 250-500, -k 5 (BASELINE configs[2])" if paired else
+                        f"{n} long reads, 5-20 kbp (mean {total / n:.0f} bp), 3% del / 3% ins / 4% sub (BASELINE configs[4]-style reads on this index)"),
+           "bases_per_s": total * steps / el, "search_ms": st.search_ms, "classified_fraction": float((res["n_match"] > 0).mean()),
+           "equals_oracle_on_first": nchk, "equals_oracle": bool(same)}
+    res_pin.free()
+    mat_pin.free()
+    dev.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +368,9 @@ def main():
     ap.add_argument("--count-sample", type=int, default=200_000, help="reads the C oracle counts operations on")
     ap.add_argument("--build-threads", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 --pmc passes (roofline.traffic then comes from profiles/pmc_latest.json)")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the paired-end / long-read legs reported under other_configs")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # child of the live PMC passes: warm-up + timed steps only
     ap.add_argument("--builder", choices=["own", "reference", "python"], default="own", help="who writes the .cfr index (outside the timed path)")
     ap.add_argument("--index-gbp", type=float, default=0.0, help="size of the synthetic index in Gbp (sets --species; same 5-strain model); "
                                                                   "0 = BASELINE configs[1] (1 Gbp, the metric's config)")
@@ -370,7 +493,11 @@ def main():
     from centrifuger_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist=dist, device=None if share_gpu else device)   # the job is as slow as its slowest rank
     classified = int((results["n_match"] > 0).sum())
-    # informational: the same step with the SDUST pre-step on the device (private copy of the reads + k_dust); never `value`
+    if args.inner:      # run under rocprofv3 by the parent bench: the timed launches are all it is for
+        if rank == 0:
+            print(json.dumps({"inner": True, "reads": args.reads, "search_ms": float(np.mean([s.search_ms for s in kstats]))}), flush=True)
+        return
+    # the same step with the SDUST pre-step on the device (private copy of the reads + k_dust); never `value`
     dev.set_dust(True)
     step()
     torch.cuda.synchronize()
@@ -401,12 +528,15 @@ def main():
                    "parallelism": f"reads sharded over {world} GPU(s), index replicated, no collective",
                    "numa_node_of_rank0": numa},
         "classified_fraction": classified / args.reads,
-        "ms_per_step_with_device_sdust": ms_with_dust,
         "stage_ms": {k: float(np.mean([getattr(s, k) for s in kstats])) for k in
                      ("pack_ms", "search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")},
     }
 
-    # ---- roofline of the dominant kernel: algorithmic bytes counted by the C oracle on a sample
+    out["with_device_sdust"] = {"value": args.reads / (ms_with_dust / 1e3), "unit": out["unit"], "ms_per_step": ms_with_dust,
+                                "note": "the same step with the reference's default pre-step (SDUST, CentrifugerClass.cpp:276-316) done on the device: "
+                                        "unmasked reads resident in HBM in, private masked copy + k_dust + the step; one process, one step timed"}
+
+    # ---- roofline of the dominant kernel
     import oracle_lib as ora
     ns = min(args.count_sample, args.reads)
     sample, soffs = sample_of(reads_d, ns)
@@ -415,25 +545,12 @@ def main():
     threads = min(os.cpu_count() or 1, 64)
     ores, cnt = o.classify(sample, soffs, sample2, soffs if paired else None, threads=threads, counters=True)
     c = cnt.as_dict()
-    # bytes of the search kernel = everything except the locate part (sampled/filter reads and the LF-walk ranks);
-    # the LF walk costs per step 1 Access + 1 Rank on the run-block structure: count it separately
+    # reference-algorithm bytes of the search part = everything except the locate part
     bytes_search = cnt.search_bytes() / ns
     bytes_locate = cnt.locate_bytes() / ns
-    locate_ms = float(np.mean([s.locate_ms for s in kstats]))
-    ach = bytes_search * args.reads / (search_ms / 1e3) / 1e9
-    traffic = requests = None
-    try:   # HBM/fabric bytes from the PMC passes of the same kernel (tools/pmc_passes.sh -> profiles/pmc_latest.json), scaled per read
-        if args.mode != "se" or args.read_len != 150:
-            raise ValueError("the committed PMC profile is of the single-end 150 bp workload")
-        pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        pm = pmj["k_search_chains_v2"]
-        traffic = (pm["fabric_read_bytes_per_read"] + pm["write_bytes_per_read"]) * args.reads
-        requests = pm["TCC_EA0_RDREQ"] / pmj["reads_in_profiled_launch"] * args.reads
-    except Exception:
-        pass
-    # what a plain device copy sustains on this box ("also report against a measured device copy bandwidth")
+    ref_alg_gbs = bytes_search * args.reads / (search_ms / 1e3) / 1e9
     copy_gbs = None
-    try:
+    try:   # what a plain device copy sustains on this box
         xa = torch.empty(1 << 31, dtype=torch.uint8, device=device)
         xb = torch.empty_like(xa)
         xb.copy_(xa)
@@ -448,31 +565,60 @@ def main():
         del xa, xb
     except Exception:
         pass
-    out["roofline"] = {
-        "bound": "hbm", "kernel": "k_search_chains_v2", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-        "measured_copy_GBs": copy_gbs,       # torch device-to-device copy of 2 GiB, read + write bytes per second
-        "algorithmic_bytes_per_read": bytes_search, "kernel_ms": search_ms,
-        "per": "one step = the launches of the step's sub-batches (achieved, traffic and kernel_ms are all summed over them)",
-        # the same kernel priced on what it really moves (PMC), and against the measured random-gather ceiling of the chip
-        "traffic_frac": (traffic / (search_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-        "gather": ({"requests_per_s": requests / (search_ms / 1e3), "ceiling_per_s": 48e9,
-                    "frac": requests / (search_ms / 1e3) / 48e9,
-                    "note": "64-byte fabric read requests of the kernel (PMC TCC_EA0_RDREQ, SE cfg2 profile, scaled per read) per second over "
-                            "tools/gather_bench's measured ceiling for dependent random 64-byte gathers at this footprint (48 G/s = 3.1 TB/s for "
-                            "tables of 16-128 GB with one load per record, 38 G/s with two loads per record as in a BWT extend; 55 G/s below 1 GB: "
-                            "profiles/r1f_gather_bench.txt)"}
-                   if requests else None),
-        "note": "achieved = reference-algorithm bytes (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, read bytes, 32 B/hit; counted by the "
-                "C oracle on a sample) / kernel time (HIP events on the library stream); the flat occ layout touches far fewer bytes",
-        "second_kernel": {"kernel": "k_locate", "algorithmic_bytes_per_read": bytes_locate, "kernel_ms": locate_ms,
-                          "achieved": bytes_locate * args.reads / (locate_ms / 1e3) / 1e9,
-                          "frac": bytes_locate * args.reads / (locate_ms / 1e3) / 1e9 / HBM_PEAK_GBS},
-        "whole_query_bytes_per_read": cnt.algorithmic_bytes() / ns,
-        "ops_per_read": {k: v / ns for k, v in c.items()},
-    }
+    def build_roofline(pmc):
+      roof = {"bound": "hbm", "kernel": "k_search_chains_v2", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": search_ms,
+              "per": "one step = the launches of the step's sub-batches (traffic and kernel_ms are summed over them)",
+              "measured_copy_GBs": copy_gbs}
+      if pmc is None and args.mode == "se" and args.read_len == 150:
+          try:    # no live passes: the committed profile of the same kernel, flagged as such
+              pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+              pm = pmj["k_search_chains_v2"]
+              pmc = {"source": f"COMMITTED profile profiles/pmc_latest.json ({pmj.get('round')}), not this run", "reads": pmj["reads_in_profiled_launch"],
+                     "rdreq": pm["TCC_EA0_RDREQ"], "rdreq_32b": pm.get("TCC_EA0_RDREQ_32B") or 0.0, "fetch_size_kib": pm["FETCH_SIZE_KiB"],
+                     "write_size_kib": pm["WRITE_SIZE_KiB"], "kernel_ms_profiled": None, "prof": None,
+                     "kernel_source_sha": pmj.get("kernel_source_sha")}
+          except Exception:
+              pmc = None
+      if pmc:
+          # calibration (profiles/r2a_gather_calib.json, tools/gather_calib.sh): a fabric read request of a random gather is one
+          # 128-byte line (two loads in the two halves of one line: 1.04 requests; FETCH_SIZE tallies it at 64 bytes)
+          per_read_rd = pmc["rdreq"] * BYTES_PER_RANDOM_REQUEST / pmc["reads"]
+          per_read_wr = pmc["write_size_kib"] * 1024 / pmc["reads"]
+          traffic = (per_read_rd + per_read_wr) * args.reads
+          ach = traffic / (search_ms / 1e3) / 1e9
+          req_s = pmc["rdreq"] / pmc["reads"] * args.reads / (search_ms / 1e3)
+          roof.update({
+              "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+              "traffic_source": pmc["source"], "kernel_source_sha_now": kernel_source_sha(), "kernel_source_sha_of_profile": pmc.get("kernel_source_sha"),
+              "fabric_read_requests_per_read": pmc["rdreq"] / pmc["reads"], "bytes_per_read_request": BYTES_PER_RANDOM_REQUEST,
+              "calibration": "profiles/r2a_gather_calib.json: random 16-byte gathers from a 32 GB table, 1.00 request per touched 128-byte line "
+                             "(both halves of a line: 1.04), 48 G requests/s = 6.2 TB/s; FETCH_SIZE counts a request as 64 bytes",
+              "read_bytes_per_read": per_read_rd, "write_bytes_per_read": per_read_wr,
+              "fetch_size_counter_bytes_per_read": pmc["fetch_size_kib"] * 1024 / pmc["reads"],
+              "kernel_ms_under_profiler_per_read_x_reads": (pmc["kernel_ms_profiled"] / pmc["reads"] * args.reads) if pmc.get("kernel_ms_profiled") else None,
+              "gather": {"requests_per_s": req_s, "ceiling_per_s": 48e9, "frac": req_s / 48e9,
+                         "note": "fabric read requests per second over tools/gather_bench's ceiling for dependent random gathers at this footprint"},
+              "note": "achieved = bytes the kernel moves over the fabric (PMC TCC_EA0_RDREQ x 128 B calibrated + WRITE_SIZE, one 2 M-read launch "
+                      "under rocprofv3 --pmc, scaled per read) / kernel time of the timed steps (HIP events on the library stream)"})
+          if pmc.get("prof"):
+              pr = pmc["prof"]
+              useful = (16 * (pr.get("table", 0) + pr.get("table10", 0)) + 48 * pr.get("ext_two_records", 0) + 24 * (pr.get("ext", 0) - pr.get("ext_two_records", 0))
+                        + 16 * pr.get("text_rows", 0) + 16 * pr.get("sa", 0) + 8 * pr.get("isa", 0) + 16 * pr.get("block_loads", 0) + 32 * c.get("hits", 0) / ns)
+              roof["useful_bytes_per_read"] = useful
+              roof["iteration_mix_per_read"] = pr
+              roof["fetched_over_useful"] = (per_read_rd + per_read_wr) / useful if useful else None
+      else:
+          roof.update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC source available (rocprofv3 failed and no committed profile for this workload)"})
+      roof["reference_algorithm"] = {
+          "bytes_per_read": bytes_search, "GBs_if_the_reference_traffic_were_moved": ref_alg_gbs, "x_of_hbm_peak": ref_alg_gbs / HBM_PEAK_GBS,
+          "note": "SURVEY.md section 8(d) figure: bytes the REFERENCE algorithm reads for the same searches (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, "
+                  "read bytes, 32 B/hit; counted exactly by the C oracle on a sample) / this kernel's time.  Above 1 because the flat occurrence "
+                  "image, the K-mer table, text mode and the locate memo do not perform that traffic - an algorithmic speed-up, not a bandwidth",
+          "locate_part_bytes_per_read": bytes_locate, "whole_query_bytes_per_read": cnt.algorithmic_bytes() / ns,
+          "ops_per_read": {kk: v / ns for kk, v in c.items()}}
+      return roof
 
-    # ---- CPU baseline: the real reference binary on this box's host cores + TSV parity on the sample
+    # ---- CPU baselines + parity
     refbin = os.path.join(ROOT, "oracle", "_ref", "centrifuger")
     if not args.no_cpu_baseline and os.path.exists(refbin) and world == 1:    # reported baseline: rank 0 at N = 1 only
         from centrifuger_amd import synth
@@ -492,14 +638,29 @@ def main():
             one2 = os.path.join(cache, "one_2.fa")
             synth.write_fasta(rs2.slice(0, 1), one2)
             files, files_one = ["-1", fa, "-2", fa2], ["-1", one, "-2", one2]
-        t0 = time.time()
-        subprocess.run([refbin, "-x", prefix, "-t", str(ncpu), "-k", str(k)] + files_one, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        t_load = time.time() - t0
-        t0 = time.time()
-        ref_tsv = subprocess.run([refbin, "-x", prefix, "-t", str(ncpu), "-k", str(k)] + files, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
-        t_full = time.time() - t0
+
+        def ref_run(t, fl, extra=()):
+            t0 = time.time()
+            o_ = subprocess.run([refbin, "-x", prefix, "-t", str(t), "-k", str(k)] + list(extra) + fl, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            return time.time() - t0, o_
+        t_load = ref_run(min(ncpu, 64), files_one)[0]
+        # thread sweep on a quarter of the sample: the reference starts its threads per batch and reads with one thread, so
+        # its best thread count is not necessarily all cores
+        nq = max(1, nb // 4)
+        sweep = {}
+        if not paired:
+            fq = os.path.join(cache, f"sample_{rank}_q.fa")
+            synth.write_fasta(rs.slice(0, nq), fq)
+            for t in sorted({32, 64, 128, ncpu}):
+                if t <= ncpu:
+                    sweep[t] = nq / max(ref_run(t, ["-u", fq])[0] - t_load, 1e-9)
+        best_t = max(sweep, key=sweep.get) if sweep else ncpu
+        t_full, ref_tsv = ref_run(best_t, files)
         cpu_rate = nb / max(t_full - t_load, 1e-9)
-        # GPU TSV on the same sample: unmasked reads in, SDUST on the device (cfr_device_index_set_dust) like the reference's pre-step
+        t_nodust, ref_tsv_nodust = ref_run(best_t, files, ["--no-dust"])
+        # (1) parity of the TIMED entry: cfr_classify_batch_resident without the pre-step == the reference run with --no-dust
+        timed_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", results[i], matches) for i in range(nb))
+        # (2) default options: unmasked reads in, SDUST on the device (cfr_device_index_set_dust) like the reference's pre-step
         b = rs.bases.copy()
         dev.set_dust(True)
         if paired:
@@ -510,32 +671,50 @@ def main():
             r2, m2 = dev.classify(b, rs.offsets)
             dev.set_dust(False)
             capi.dust_mask(b, rs.offsets, threads=min(ncpu, 64))      # the timed legs below take masked reads (the Query contract)
-            # the same entry once more, timed: host (pageable) buffers in, host buffers out = the PCIe-inclusive rate (never `value`)
             dev.classify(b, rs.offsets)                                   # untimed: page in, size the staging buffers
             t0 = time.perf_counter()
             dev.classify(b, rs.offsets)
             out["pcie_inclusive"] = {"value": nb / (time.perf_counter() - t0), "unit": "reads/s",
                                      "note": f"cfr_classify_batch on {nb} reads from pageable host memory to pageable host memory (H2D 150 B/read, D2H 64 B/read)"}
-            # and the whole step batch with every host buffer pinned (cfr_host_alloc): the bases of sub-batch k+1 go up while
-            # sub-batch k computes, so the call is bound by the H2D copy (150 B/read)
+            # the whole step batch with every host buffer pinned (cfr_host_alloc): the bases of sub-batch k+1 go up while sub-batch k computes
             pb = capi.PinnedArray(total_bases, np.uint8)
             po = capi.PinnedArray(args.reads + 1, np.uint64)
             pb.array[:] = reads_d.reshape(-1).cpu().numpy()
             po.array[:] = offs_h
+            res_keep = results[:nb].copy()
             dev.classify(pb.array, po.array, results=results, matches=matches)
             t0 = time.perf_counter()
             dev.classify(pb.array, po.array, results=results, matches=matches)
             out["pcie_inclusive"]["pinned_value"] = args.reads / (time.perf_counter() - t0)
             out["pcie_inclusive"]["pinned_note"] = f"{args.reads} reads, bases / offsets / results / matches all in cfr_host_alloc memory"
+            out["pcie_inclusive"]["host_entry_equals_resident_entry"] = bool(res_keep.tobytes() == results[:nb].tobytes())
             pb.free()
             po.free()
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
-        out["cpu_baseline"] = {"value": cpu_rate, "unit": "reads/s", "cores": ncpu, "kind": "reference",
-                               "sample": f"first {nb} {'pairs' if paired else 'reads'} of the step batch, oracle/_ref/centrifuger -t {ncpu} -k {k}, "
-                                         f"wall {t_full:.1f}s minus index-load run {t_load:.1f}s (end-to-end incl. FASTA parse, dust, TSV)"}
-        out["parity"] = {"reads": nb, "tsv_identical_to_reference": gpu_tsv == ref_tsv,
-                         "md5": hashlib.md5(gpu_tsv).hexdigest()}
-        out["speedup_vs_cpu"] = value / world / cpu_rate
+        out["cpu_baseline"] = {"value": cpu_rate, "unit": out["unit"], "cores": best_t, "kind": "reference",
+                               "sample": f"first {nb} {'pairs' if paired else 'reads'} of the step batch, oracle/_ref/centrifuger -t {best_t} -k {k} "
+                                         f"(best of the thread sweep), wall {t_full:.1f}s minus index-load run {t_load:.1f}s: END TO END (FASTA parse, dust, classify, TSV)",
+                               "thread_sweep_reads_per_s": {str(t): v for t, v in sweep.items()}, "host_cores": ncpu,
+                               "no_dust_value": nb / max(t_nodust - t_load, 1e-9)}
+        # classify-only on the host cores: the C restatement (oracle, same data structures as the reference) without parse / dust / output
+        try:
+            nco = min(nb, 1_000_000)
+            cs, co = sample_of(reads_d, nco)
+            cs2 = sample_of(reads2_d, nco)[0] if paired else None
+            capi.dust_mask(cs, co, threads=min(ncpu, 64))
+            t0 = time.perf_counter()
+            o.classify(cs, co, cs2, co if paired else None, dust=False, threads=ncpu)
+            out["cpu_baseline"]["classify_only"] = {"value": nco / (time.perf_counter() - t0), "kind": "port", "cores": ncpu,
+                                                    "sample": f"{nco} masked reads through oracle/liboracle.so (Query only: no parse, no dust, no TSV)"}
+        except Exception as e:
+            out["cpu_baseline"]["classify_only"] = {"error": str(e)}
+        out["parity"] = {"reads": nb,
+                         "timed_entry_tsv_identical_to_reference_no_dust": timed_tsv == ref_tsv_nodust,
+                         "tsv_identical_to_reference": gpu_tsv == ref_tsv,
+                         "md5": hashlib.md5(gpu_tsv).hexdigest(), "md5_timed_entry": hashlib.md5(timed_tsv).hexdigest(),
+                         "note": "timed entry = cfr_classify_batch_resident, the call `value` times (reads as they are, no pre-step) vs `centrifuger --no-dust`; "
+                                 "the second check hands unmasked reads to cfr_classify_batch with SDUST on the device vs the reference's default run"}
+        out["kernel_vs_e2e_cpu"] = value / world / cpu_rate      # resident-input device step over the END-TO-END reference: not like for like (see e2e_cli.speedup)
         # ---- end-to-end wall clock of the drop-in command line on the same file (parse + dust + device + TSV, index load included)
         cli = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
         if os.path.exists(cli):
@@ -545,7 +724,22 @@ def main():
             t_cli = time.time() - t0
             out["e2e_cli"] = {"reads": nb, "seconds": t_cli, "reference_seconds": t_full, "speedup": t_full / t_cli,
                               "tsv_identical_to_reference": cli_tsv == ref_tsv,
-                              "note": "wall clock of `centrifuger -x idx ...` on the sample file, index load / device image included on both sides"}
+                              "note": "wall clock of `centrifuger -x idx ...` on the sample file, index load / device image included on both sides: "
+                                      "the like-for-like ratio"}
+    # ---- the live PMC passes need the GPU to themselves (the K-mer table is sized from the free HBM): this process lets go of
+    # its image and reads first, so the child builds exactly the image that was timed
+    dev.close()
+    del reads_d, reads2_d
+    torch.cuda.empty_cache()
+    out["roofline"] = build_roofline(live_pmc(args, cache) if (world == 1 and not args.no_pmc) else None)
+    # ---- the other BASELINE configs on the same index, as sub-results (configs[2] paired-end -k 5, configs[4]-style long reads)
+    if world == 1 and args.mode == "se" and not args.no_extra_configs and not args.inner:
+        out["other_configs"] = {}
+        for m in ("pe", "long"):
+            try:
+                out["other_configs"][m] = extra_config(torch, capi, ora, args, m, prefix, cache, device)
+            except Exception as e:
+                out["other_configs"][m] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -214,6 +214,53 @@ uint64_t ora_rb_rank(const ora_runblock *s, char ch, uint64_t i, int inclusive, 
   return ret;
 }
 
+/* Sequence_RunBlockOneTree::Load (Sequence_RunBlockOneTree.hpp:499-513) */
+static int rb1_load(FILE *fp, ora_runblock1 *s) {
+  uint64_t space;
+  memset(s, 0, sizeof(*s));
+  RD(fp, space); RD(fp, s->n);
+  if (alphabet_load(fp, &s->alphabet)) return -1;
+  RD(fp, s->b); RD(fp, s->blockCnt);
+  if (bv_load(fp, &s->useRunBlock)) return -1;
+  s->alphabetRB = xcalloc(s->alphabet.n ? s->alphabet.n : 1, sizeof(ora_bitvec));
+  for (uint64_t i = 0; i < s->alphabet.n; ++i) if (bv_load(fp, &s->alphabetRB[i])) return -1;
+  if (wt_load(fp, &s->compressedSeq)) return -1;
+  return 0;
+}
+static void rb1_free(ora_runblock1 *s) {
+  bv_free(&s->useRunBlock);
+  if (s->alphabetRB) for (uint64_t i = 0; i < s->alphabet.n; ++i) bv_free(&s->alphabetRB[i]);
+  free(s->alphabetRB);
+  wt_free(&s->compressedSeq);
+}
+/* Sequence_RunBlockOneTree::Access (:382-396) */
+char ora_rb1_access(const ora_runblock1 *s, uint64_t i, ora_counters *c) {
+  uint64_t bi = i / s->b;
+  uint64_t r = ora_bv_rank(&s->useRunBlock, 1, bi, 0, c);
+  int type = ora_bv_access(&s->useRunBlock, bi, c);
+  if (type == 1) i -= i % s->b;            /* the "representative" position of a run block */
+  i -= (s->b - 1) * r;                      /* every run block before takes b-1 positions out */
+  return ora_wt_access(&s->compressedSeq, i, c);
+}
+/* Sequence_RunBlockOneTree::Rank (:398-435) */
+uint64_t ora_rb1_rank(const ora_runblock1 *s, char ch, uint64_t i, int inclusive, ora_counters *c) {
+  if (!inclusive) { if (i == 0) return 0; --i; }
+  uint64_t bi = i / s->b;
+  uint64_t r = ora_bv_rank(&s->useRunBlock, 1, bi, 0, c);
+  int type = ora_bv_access(&s->useRunBlock, bi, c);
+  uint64_t remainder = 0, ci = i;
+  if (type == 1) { remainder = i % s->b; ci -= i % s->b; }
+  ci -= (s->b - 1) * r;
+  uint64_t ret;
+  int inRun = 0;
+  if (type == 1) ret = ora_wt_rank_and_test(&s->compressedSeq, ch, ci, &inRun, c);
+  else ret = ora_wt_rank(&s->compressedSeq, ch, ci, 1, c);
+  if (ret > 0 && (s->b < s->n || inRun))
+    ret += ora_bv_rank(&s->alphabetRB[s->alphabet.code[(unsigned char)ch]], 1, ret - 1, 1, c) * (s->b - 1);
+  if (inRun) ret = ret - (s->b - 1) + remainder;
+  return ret;
+}
+
 /* ======================================================================== FixedSizeElemArray */
 
 /* FixedSizeElemArray::Load (:396-404) */
@@ -280,23 +327,27 @@ static int aux_load(FILE *fp, ora_fm *fm) {
 }
 
 /* FMIndex::Load (FMIndex.hpp:588-606) */
-static int fm_load(FILE *fp, ora_fm *fm) {
+static int fm_load(FILE *fp, ora_fm *fm, int oneTree) {
   memset(fm, 0, sizeof(*fm));
+  fm->oneTree = oneTree;
   RD(fp, fm->n); RD(fp, fm->plainAlphabetBits); RD(fp, fm->firstISA); RD(fp, fm->lastChr);
-  if (rb_load(fp, &fm->bwt)) return -1;
+  if (oneTree ? rb1_load(fp, &fm->bwt1) : rb_load(fp, &fm->bwt)) return -1;
   if (alphabet_load(fp, &fm->alphabets)) return -1;
   if (alphabet_load(fp, &fm->plainCoder)) return -1;
   if (rd(fp, fm->C, 8, fm->plainCoder.n + 1)) return -1;
   return aux_load(fp, fm);
 }
 static void fm_free(ora_fm *fm) {
-  rb_free(&fm->bwt); free(fm->sampledSA.W); free(fm->precomputedRange);
+  rb_free(&fm->bwt); rb1_free(&fm->bwt1); free(fm->sampledSA.W); free(fm->precomputedRange);
   free(fm->selectedRows); free(fm->selectedVals); free(fm->selectedFilter); free(fm->endMarkerSA.W);
 }
 
 /* FMIndex::Rank (:352-362) */
+char ora_fm_access(const ora_fm *fm, uint64_t i, ora_counters *c) {
+  return fm->oneTree ? ora_rb1_access(&fm->bwt1, i, c) : ora_rb_access(&fm->bwt, i, c);
+}
 uint64_t ora_fm_rank(const ora_fm *fm, char ch, uint64_t p, int inclusive, ora_counters *c) {
-  uint64_t ret = ora_rb_rank(&fm->bwt, ch, p, inclusive, c);
+  uint64_t ret = fm->oneTree ? ora_rb1_rank(&fm->bwt1, ch, p, inclusive, c) : ora_rb_rank(&fm->bwt, ch, p, inclusive, c);
   if (ch == fm->lastChr && (p < fm->firstISA || (!inclusive && p == fm->firstISA))) ++ret;
   return ret;
 }
@@ -307,7 +358,7 @@ void ora_fm_backward_extend(const ora_fm *fm, char ch, uint64_t sp, uint64_t ep,
   if (c) { c->extends++; if (sp == ep) c->ext_single_row++; else if ((sp >> 7) != (ep >> 7)) c->ext_two_records++; }
   *nsp = offset + ora_fm_rank(fm, ch, sp, 0, c) + 1 - 1;
   if (sp != ep) *nep = offset + ora_fm_rank(fm, ch, ep, 1, c) - 1;
-  else *nep = *nsp + ((ora_rb_access(&fm->bwt, ep, c) == ch) ? 0 : (uint64_t)-1);
+  else *nep = *nsp + ((ora_fm_access(fm, ep, c) == ch) ? 0 : (uint64_t)-1);
 }
 /* FMIndex::BackwardExtend LF form (:382-386) */
 uint64_t ora_fm_lf(const ora_fm *fm, char ch, uint64_t p, ora_counters *c) {
@@ -374,7 +425,7 @@ uint64_t ora_fm_backward_to_sampled_sa(const ora_fm *fm, uint64_t i, uint64_t *l
   uint64_t r0 = 0, a0 = 0;
   if (c) { c->locates++; r0 = c->bitrank; a0 = c->bitaccess; }
   while (!fm_get_sampled_sa(fm, i, &ret, c)) {
-    i = ora_fm_lf(fm, ora_rb_access(&fm->bwt, i, c), i, c);
+    i = ora_fm_lf(fm, ora_fm_access(fm, i, c), i, c);
     if (c) c->lf_steps++;
     ++*l;
   }
@@ -593,11 +644,11 @@ static uint64_t power_int(int x, int y) {   /* Utils::PowerInt (Utils.hpp:164-17
 ora_index *ora_index_load(const char *prefix, const ora_param *param) {   /* Classifier::Init (:902-947) */
   ora_index *idx = xcalloc(1, sizeof(*idx));
   char *name = xmalloc(strlen(prefix) + 17);
-  if (ora_is_protein_index(prefix)) { fprintf(stderr, "oracle: protein indexes are out of scope\n"); goto fail; }
+  idx->protein = ora_is_protein_index(prefix);
   sprintf(name, "%s.1.cfr", prefix);
   FILE *fp = fopen(name, "rb");
   if (!fp) { fprintf(stderr, "oracle: cannot open %s\n", name); goto fail; }
-  int rc = fm_load(fp, &idx->fm);
+  int rc = fm_load(fp, &idx->fm, idx->protein);
   fclose(fp);
   if (rc) { fprintf(stderr, "oracle: malformed %s\n", name); goto fail; }
   sprintf(name, "%s.2.cfr", prefix);
@@ -609,8 +660,9 @@ ora_index *ora_index_load(const char *prefix, const ora_param *param) {   /* Cla
   free(name);
   if (param) idx->param = *param; else ora_param_default(&idx->param);
   idx->scoreHitLenAdjust = 15;
+  if (idx->protein) idx->scoreHitLenAdjust /= 3;      /* Classifier.hpp:928-932 */
   if (idx->param.minHitLen <= 0) {   /* InferMinHitLen (:113-129) */
-    int mhl = 23;
+    int mhl = idx->protein ? 11 : 23;
     int asz = (int)idx->fm.alphabets.n;
     uint64_t kmerspace = power_int(asz, mhl) / 2;
     for (; mhl <= 32; ++mhl) { if (kmerspace >= 100 * idx->fm.n) break; kmerspace *= (uint64_t)asz; }
@@ -732,23 +784,85 @@ static char *revcomp_dup(const char *r, int len) {
   return rc;
 }
 
-/* Classifier::SearchForwardAndReverse (:509-583), nucleotide branch */
+/* Classifier::DnaToAa (:131-241): an if/else ladder, so every character that is not one of the letters it tests takes the
+ * last branch of its level (a == anything but A,C,G behaves as T, and so on); only 'N' gives '?' */
+char ora_dna_to_aa(char a, char b, char c) {
+  if (a == 'N' || b == 'N' || c == 'N') return '?';
+  const int ag = (c == 'A' || c == 'G');
+  if (a == 'A') {
+    if (b == 'A') return ag ? 'K' : 'N';
+    if (b == 'C') return 'T';
+    if (b == 'G') return ag ? 'R' : 'S';
+    return c == 'G' ? 'M' : 'I';
+  } else if (a == 'C') {
+    if (b == 'A') return ag ? 'Q' : 'H';
+    if (b == 'C') return 'P';
+    if (b == 'G') return 'R';
+    return 'L';
+  } else if (a == 'G') {
+    if (b == 'A') return ag ? 'E' : 'D';
+    if (b == 'C') return 'A';
+    if (b == 'G') return 'G';
+    return 'V';
+  } else {
+    if (b == 'A') return ag ? '_' : 'Y';
+    if (b == 'C') return 'S';
+    if (b == 'G') return c == 'A' ? '_' : (c == 'G' ? 'W' : 'C');
+    return ag ? 'L' : 'F';
+  }
+}
+/* Classifier::TranslatedSearch (:463-506): the three frames of r, the frame with the highest "score" wins - where the score
+ * of a frame is (number of its hits) x (sum of its hit scores): the loop at :489-493 adds the whole list's score once per hit */
+static size_t translated_search(const ora_index *idx, const char *r, int rlen, ora_hitvec *hits, ora_counters *c) {
+  char *aa = xmalloc((size_t)rlen + 1);
+  ora_hitvec frameHits[3] = {{0}, {0}, {0}};
+  for (int frame = 0; frame < 3; ++frame) {
+    int k = 0;
+    for (int i = frame; i + 2 < rlen; i += 3) aa[k++] = ora_dna_to_aa(r[i], r[i + 1], r[i + 2]);
+    aa[k] = 0;
+    ora_get_hits_from_read(idx, aa, (size_t)k, &frameHits[frame], c);
+  }
+  uint64_t maxScore = 0;
+  int maxTag = 0;
+  for (int frame = 0; frame < 3; ++frame) {
+    uint64_t score = 0;
+    for (size_t i = 0; i < frameHits[frame].n; ++i) score += hits_score(idx, &frameHits[frame]);
+    if (score > maxScore) { maxScore = score; maxTag = frame; }
+  }
+  size_t ret = frameHits[maxTag].n;
+  hit_append(hits, &frameHits[maxTag]);
+  for (int frame = 0; frame < 3; ++frame) ora_hitvec_free(&frameHits[frame]);
+  free(aa);
+  return ret;
+}
+
+/* Classifier::SearchForwardAndReverse (:509-583) */
 size_t ora_search_forward_and_reverse(const ora_index *idx, const char *r1, const char *r2, ora_hitvec *hits, ora_counters *c) {
   int r1len = (int)strlen(r1);
   char *rcR1 = revcomp_dup(r1, r1len), *rcR2 = NULL;
   ora_hitvec strandHits[2] = {{0}, {0}};
   if (c) c->read_bases += (uint64_t)r1len;
+  if (idx->protein) {
+    translated_search(idx, r1, r1len, &strandHits[1], c);
+    translated_search(idx, rcR1, r1len, &strandHits[0], c);
+  } else {
   ora_get_hits_from_read(idx, r1, (size_t)r1len, &strandHits[1], c);
   ora_get_hits_from_read(idx, rcR1, (size_t)r1len, &strandHits[0], c);
   ora_adjust_hit_boundary(idx, r1, rcR1, r1len, strandHits, c);
+  }
   if (r2) {
     int r2len = (int)strlen(r2);
     rcR2 = revcomp_dup(r2, r2len);
     if (c) c->read_bases += (uint64_t)r2len;
     ora_hitvec r2Hits[2] = {{0}, {0}};
+    if (idx->protein) {
+      translated_search(idx, r2, r2len, &r2Hits[1], c);
+      translated_search(idx, rcR2, r2len, &r2Hits[0], c);
+    } else {
     ora_get_hits_from_read(idx, r2, (size_t)r2len, &r2Hits[1], c);
     ora_get_hits_from_read(idx, rcR2, (size_t)r2len, &r2Hits[0], c);
     ora_adjust_hit_boundary(idx, r2, rcR2, r2len, r2Hits, c);
+    }
     for (int i = 0; i <= 1; ++i) hit_append(&strandHits[i], &r2Hits[1 - i]);
     ora_hitvec_free(&r2Hits[0]); ora_hitvec_free(&r2Hits[1]);
   }
@@ -1086,7 +1200,7 @@ static void *batch_thread(void *p) {   /* ClassifyReads_Thread (CentrifugerClass
     }
     memcpy(s1, a->b1 + a->o1[i], l1); s1[l1] = 0;
     if (a->b2) { memcpy(s2, a->b2 + a->o2[i], l2); s2[l2] = 0; }
-    if (a->dust) { ora_dust_mask_inplace(s1, l1); if (a->b2) ora_dust_mask_inplace(s2, l2); }
+    if (a->dust && !a->idx->protein) { ora_dust_mask_inplace(s1, l1); if (a->b2) ora_dust_mask_inplace(s2, l2); }   /* CentrifugerClass.cpp:276 */
     ora_query(a->idx, s1, a->b2 ? s2 : NULL, &a->res[i], &a->cnt);
   }
   free(s1); free(s2);

@@ -66,6 +66,16 @@ typedef struct {
   ora_wavelet waveletSeq, runBlockSeq;
 } ora_runblock;
 
+/* ---- L1: run-block sequence over ONE wavelet tree (Sequence_RunBlockOneTree.hpp:15-21): protein indexes ---- */
+typedef struct {
+  uint64_t n;
+  ora_alphabet alphabet;
+  uint64_t b, blockCnt;
+  ora_bitvec useRunBlock;
+  ora_bitvec *alphabetRB;     /* one per alphabet symbol */
+  ora_wavelet compressedSeq;
+} ora_runblock1;
+
 /* ---- FixedSizeElemArray (FixedSizeElemArray.hpp) ---- */
 typedef struct {
   uint64_t size;   /* words */
@@ -78,7 +88,9 @@ typedef struct {
 typedef struct {
   uint64_t n, plainAlphabetBits, firstISA;
   char lastChr;
+  int oneTree;              /* FMIndex<Sequence_RunBlockOneTree> (protein, CentrifugerClass.cpp:1001-1004) */
   ora_runblock bwt;
+  ora_runblock1 bwt1;
   ora_alphabet alphabets, plainCoder;
   uint64_t C[257];
   /* aux data */
@@ -121,7 +133,8 @@ typedef struct {
   ora_fm fm;
   ora_taxonomy tax;
   ora_param param;
-  int scoreHitLenAdjust;  /* 15 */
+  int scoreHitLenAdjust;  /* 15; 5 for a protein index (Classifier.hpp:928-932) */
+  int protein;            /* Classifier::_protein: translated search, no dust */
 } ora_index;
 
 /* operation counters: the N's of SURVEY.md §8(d) "algorithmic bytes" */
@@ -169,6 +182,10 @@ uint64_t ora_wt_rank_and_test(const ora_wavelet *w, char ch, uint64_t i, int *is
 char ora_wt_access(const ora_wavelet *w, uint64_t i, ora_counters *c);
 uint64_t ora_rb_rank(const ora_runblock *s, char ch, uint64_t i, int inclusive, ora_counters *c);
 char ora_rb_access(const ora_runblock *s, uint64_t i, ora_counters *c);
+uint64_t ora_rb1_rank(const ora_runblock1 *s, char ch, uint64_t i, int inclusive, ora_counters *c);
+char ora_rb1_access(const ora_runblock1 *s, uint64_t i, ora_counters *c);
+char ora_fm_access(const ora_fm *fm, uint64_t i, ora_counters *c);    /* _BWT.Access on whichever sequence class the index holds */
+char ora_dna_to_aa(char a, char b, char c);                           /* Classifier::DnaToAa (Classifier.hpp:131-241) */
 uint64_t ora_fsea_read(const ora_fsea *a, uint64_t i);
 
 uint64_t ora_fm_rank(const ora_fm *fm, char ch, uint64_t p, int inclusive, ora_counters *c);

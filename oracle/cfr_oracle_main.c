@@ -91,11 +91,12 @@ int main(int argc, char **argv) {
   const ora_fm *fm = &idx->fm;
 
   if (!strcmp(cmd, "dump-rank")) {
-    const char *A = "ACGT";
+    const char *A = idx->protein ? "$ARNDCEQGHILKMFPSTWYV" : "ACGT";      /* protein: ref_dump's prank stream */
+    const int na = (int)strlen(A);
     for (uint64_t i = 0; i < fm->n; i += step) {
-      printf("%lu %c", (unsigned long)i, ora_rb_access(&fm->bwt, i, NULL));
+      printf("%lu %c", (unsigned long)i, ora_fm_access(fm, i, NULL));
       for (int inc = 1; inc >= 0; --inc)
-        for (int c = 0; c < 4; ++c) printf(" %lu", (unsigned long)ora_fm_rank(fm, A[c], i, inc, NULL));
+        for (int c = 0; c < na; ++c) printf(" %lu", (unsigned long)ora_fm_rank(fm, A[c], i, inc, NULL));
       printf("\n");
     }
     return 0;

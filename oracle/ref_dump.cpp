@@ -15,6 +15,7 @@ char numToNuc[26] ;
 
 #include "compactds/FMIndex.hpp"
 #include "compactds/Sequence_RunBlock.hpp"
+#include "compactds/Sequence_RunBlockOneTree.hpp"
 
 using namespace compactds ;
 
@@ -39,7 +40,35 @@ static std::vector<std::string> ReadSeqs(const char *path)
 
 int main(int argc, char *argv[])
 {
-  if (argc < 3) { fprintf(stderr, "usage: ref_dump <rank|locate|bs> idx.1.cfr [step|reads]\n") ; return 1 ; }
+  if (argc < 3) { fprintf(stderr, "usage: ref_dump <rank|locate|bs|prank|plocate> idx.1.cfr [step|reads]\n") ; return 1 ; }
+  if (argv[1][0] == 'p')     // protein index: FMIndex<Sequence_RunBlockOneTree> (CentrifugerClass.cpp:1001-1004)
+  {
+    FMIndex<Sequence_RunBlockOneTree> pfm ;
+    FILE *pfp = fopen(argv[2], "r") ;
+    if (!pfp) { fprintf(stderr, "cannot open %s\n", argv[2]) ; return 1 ; }
+    pfm.Load(pfp) ;
+    fclose(pfp) ;
+    const size_t pn = pfm.GetSize() ;
+    const char *PA = "$ARNDCEQGHILKMFPSTWYV" ;
+    const size_t step = argc > 3 ? strtoull(argv[3], NULL, 10) : 1 ;
+    if (!strcmp(argv[1], "prank"))
+      for (size_t i = 0 ; i < pn ; i += step)
+      {
+        printf("%lu %c", i, pfm.GetBWT()->Access(i)) ;
+        for (int inc = 1 ; inc >= 0 ; --inc)
+          for (int c = 0 ; c < 21 ; ++c)
+            printf(" %lu", pfm.Rank(PA[c], i, inc)) ;
+        printf("\n") ;
+      }
+    else
+      for (size_t i = 0 ; i < pn ; i += step)
+      {
+        size_t l ;
+        size_t v = pfm.BackwardToSampledSA(i, l) ;
+        printf("%lu %lu %lu\n", i, v, l) ;
+      }
+    return 0 ;
+  }
   FMIndex<Sequence_RunBlock> fm ;
   FILE *fp = fopen(argv[2], "r") ;
   if (!fp) { fprintf(stderr, "cannot open %s\n", argv[2]) ; return 1 ; }

@@ -10,7 +10,7 @@ import pytest
 
 from centrifuger_amd import capi, synth
 from cfr_fields import parse_1cfr
-from conftest import GOLDEN, REF_DIR, have_ref
+from conftest import GOLDEN, REF_DIR, ROOT, have_ref
 
 pytestmark = pytest.mark.gpu
 MAN = json.load(open(os.path.join(GOLDEN, "manifest.json")))
@@ -88,8 +88,17 @@ def test_native_writer_equals_reference_builder_on_a_fresh_3mbp_text(tmp_path):
                    check=True, stderr=subprocess.DEVNULL)
     prefix = str(tmp_path / "own")
     capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
-    mine, ref = parse_1cfr(prefix + ".1.cfr"), parse_1cfr(ref_prefix + ".1.cfr")
-    assert len(mine) == len(ref)
-    for (na, va), (nb, vb) in zip(mine, ref):
-        assert na == nb and va == vb, f"field {na} differs"
-    assert open(prefix + ".2.cfr", "rb").read() == open(ref_prefix + ".2.cfr", "rb").read()
+    # and through the drop-in command line (same files the reference's builder read, gz'd FASTA)
+    cli_prefix = str(tmp_path / "cli")
+    subprocess.run(["gzip", "-1", str(tmp_path / "ref.fa")], check=True)
+    subprocess.run([os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger-build"), "-t", "8", "-r", str(tmp_path / "ref.fa.gz"), "--taxonomy-tree",
+                    str(tmp_path / "nodes.dmp"), "--name-table", str(tmp_path / "names.dmp"), "--conversion-table", str(tmp_path / "seqid.map"),
+                    "-o", cli_prefix, "--bmax", "1000000"], check=True, stderr=subprocess.DEVNULL)
+    ref = parse_1cfr(ref_prefix + ".1.cfr")
+    for pre in (prefix, cli_prefix):
+        mine = parse_1cfr(pre + ".1.cfr")
+        assert len(mine) == len(ref)
+        for (na, va), (nb, vb) in zip(mine, ref):
+            assert na == nb and va == vb, f"field {na} differs"
+        assert open(pre + ".2.cfr", "rb").read() == open(ref_prefix + ".2.cfr", "rb").read()
+        assert open(pre + ".3.cfr", "rb").read() == open(ref_prefix + ".3.cfr", "rb").read()

@@ -3,9 +3,19 @@
 usage: pmc_latest.py <pmc dir> <round tag> <out json>"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha():      # the same digest bench.py computes: tells a reader whether the profile is of the benched kernels
+    h = hashlib.sha1()
+    for f in ("cfr_kernels.hip.inc", "cfr_device.hip", "cfr_device.hpp"):
+        h.update(open(os.path.join(ROOT, "centrifuger_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def main(d, tag, out):
@@ -16,13 +26,13 @@ def main(d, tag, out):
                 vals[row["Counter_Name"]] = float(row["Counter_Value"])      # last dispatch wins = the timed step
     reads = json.load(open(os.path.join(d, "bench_plain.json")))["config"]["reads_per_step_per_gpu"]
     res = {"round": tag, "source": f"profiles/{tag}_pmc_summary.txt (rocprofv3 --pmc, separate passes, {reads}-read launch, 1 Gbp index)",
-           "reads_in_profiled_launch": reads,
+           "reads_in_profiled_launch": reads, "kernel_source_sha": kernel_source_sha(),
            "k_search_chains_v2": {
                "FETCH_SIZE_KiB": vals.get("FETCH_SIZE"), "TCC_EA0_RDREQ": vals.get("TCC_EA0_RDREQ_sum"),
                "TCC_EA0_RDREQ_32B": vals.get("TCC_EA0_RDREQ_32B_sum"), "WRITE_SIZE_KiB": vals.get("WRITE_SIZE"),
                "fabric_read_bytes_per_read": vals["FETCH_SIZE"] * 1024 / reads, "write_bytes_per_read": vals["WRITE_SIZE"] * 1024 / reads,
-               "note": "FETCH_SIZE == TCC_EA0_RDREQ x 64 B (all requests are 64 B; random gathers, so the streaming half-count "
-                       "correction of the guide does not apply)"}}
+               "note": "FETCH_SIZE == TCC_EA0_RDREQ x 64 B is the counter's tally; calibrated on this chip a random gather's request carries a "
+                       "128-byte line (profiles/r2a_gather_calib.json), so fabric bytes = TCC_EA0_RDREQ x 128 (what bench.py uses)"}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["k_search_chains_v2"]))
 
