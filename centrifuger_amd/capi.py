@@ -31,7 +31,7 @@ class Params(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("n", C.c_uint64), ("first_isa", C.c_uint64), ("block_size", C.c_uint64), ("precompute_width", C.c_uint64),
                 ("sample_rate", C.c_uint64), ("selected_cnt", C.c_uint64), ("seq_cnt", C.c_uint64), ("node_cnt", C.c_uint64),
-                ("min_hit_len", C.c_int32), ("last_chr", C.c_char), ("pad", C.c_char * 3), ("device_bytes", C.c_uint64)]
+                ("min_hit_len", C.c_int32), ("last_chr", C.c_char), ("is_protein", C.c_uint8), ("pad", C.c_char * 2), ("device_bytes", C.c_uint64)]
 
 
 class BatchStats(C.Structure):

@@ -36,7 +36,7 @@ void fill_info(const cfr::HostIndex &h, cfr_index_info *info, uint64_t dev_bytes
   info->n = h.n; info->first_isa = h.first_isa; info->block_size = h.b; info->precompute_width = h.precompute_width;
   info->sample_rate = (uint64_t)h.sample_rate; info->selected_cnt = h.selected_rows.size();
   info->seq_cnt = h.tax.seq_cnt; info->node_cnt = h.tax.node_cnt; info->min_hit_len = h.params.min_hit_len;
-  info->last_chr = h.last_chr; info->device_bytes = dev_bytes;
+  info->last_chr = h.last_chr; info->is_protein = h.prot.enabled ? 1 : 0; info->device_bytes = dev_bytes;
 }
 
 int default_tail_threads() {

@@ -488,6 +488,15 @@ int main(int argc, char *argv[]) {
   // dust stage (CentrifugerClass.cpp:276-316): needs no index either
   // The masking itself runs on the device inside the classify call (cfr_device_index_set_dust); the host stage only works
   // when the masked reads are needed on the host as well (--un / --cl write them).
+  // a protein index (.4.cfr says sequence_type amino_acid, Classifier::IsProteinDatabase) is searched translated and never
+  // dust-masked (CentrifugerClass.cpp:248, 276); the stage below must know before the index itself is loaded
+  bool protein = false;
+  if (FILE *f4 = fopen((opt.idx + ".4.cfr").c_str(), "r")) {
+    char key[128], val[128];
+    while (fscanf(f4, "%127s %127s", key, val) == 2) if (!strcmp(key, "sequence_type") && !strcmp(val, "amino_acid")) protein = true;
+    fclose(f4);
+  }
+  if (protein) opt.dust = false;
   const bool host_dust = opt.dust && (!opt.un_prefix.empty() || !opt.cl_prefix.empty());
   WorkerPool dust_pool(host_dust ? opt.threads : 1), format_pool(opt.threads);
   std::thread duster([&]() {
@@ -527,6 +536,7 @@ int main(int argc, char *argv[]) {
   clk.add(T_OPEN, t0);
   cfr_index_info info;
   cfr_index_get_info(idx, &info);
+  if (info.is_protein) print_log("This is a protein database and will use translated search.");
   print_log("Finishes loading index.");
   if (opt.params.min_hit_len <= 0) print_log("Inferred --min-hitlen: %d", info.min_hit_len);
   std::vector<cfr_dev_index *> devs;

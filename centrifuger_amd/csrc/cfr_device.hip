@@ -127,8 +127,38 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   bool layout_rb = opt.run_block_layout != 0;
   if (const char *e = dbg_env("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
   memset(&view_.rb, 0, sizeof(view_.rb));
+  memset(&view_.prot, 0, sizeof(view_.prot));
   uint64_t *d_occ = nullptr;
-  {
+  if (h.prot.enabled) {
+    // ---- protein image: bit planes + per-block counts of the decoded BWT (cfr_device.hpp ProtView)
+    const ProteinPart &P = h.prot;
+    const uint64_t nblk = (h.n >> 6) + 2;
+    std::vector<uint64_t> planes(nblk * 8, 0), counts(nblk * 32, 0);
+    uint64_t run[32] = {0};
+    for (uint64_t blk = 0; blk < nblk; ++blk) {
+      for (int k = 0; k < 32; ++k) counts[blk * 32 + (uint64_t)k] = run[k];
+      for (uint64_t j = 0; j < 64; ++j) {
+        const uint64_t p = blk * 64 + j;
+        if (p >= h.n) break;
+        const uint32_t c = P.bwt[p];
+        for (int k = 0; k < 5; ++k) planes[blk * 8 + (uint64_t)k] |= (uint64_t)((c >> k) & 1u) << j;
+        ++run[c];
+      }
+    }
+    view_.prot.enabled = 1;
+    view_.prot.sigma = P.sigma;
+    view_.prot.bits = P.bits;
+    view_.prot.planes = upload(planes);
+    view_.prot.counts = upload(counts);
+    view_.prot.endmarker_bits = (uint32_t)P.end_marker_bits;
+    view_.prot.endmarker_n = P.end_marker_n;
+    view_.prot.endmarker = upload(P.end_marker_words.empty() ? std::vector<uint64_t>(2, 0) : P.end_marker_words);
+    view_.prot.code_of = upload(std::vector<uint8_t>(P.code_of, P.code_of + 256));
+    for (uint32_t k = 0; k <= P.sigma; ++k) view_.prot.C[k] = P.C[k];
+    memcpy(view_.prot.list, P.list, 32);
+    search_v1_ = true;                   // (the state-machine kernel is a nucleotide kernel)
+    lap("protein image (host) + upload");
+  } else {
     // ---- run-block image: the 7 bitvectors as rank lines (cfr_device.hpp).  CFR_LAYOUT=rb searches on it directly;
     // otherwise it is only the source the flat occ image is expanded from (on the device) and is freed afterwards.
     std::vector<void *> rb_allocs;
@@ -227,6 +257,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   view_.first_isa = h.first_isa;
   view_.adjusted_sa0 = h.adjusted_sa0;
   memcpy(view_.C, h.C, sizeof(h.C));
+  const bool protein = h.prot.enabled;
   view_.occ = d_occ;
   view_.ftab = d_ftab;
   view_.sampled = d_sampled;
@@ -281,6 +312,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;
+    if (protein) K = 0;                  // derived K-mer table and text mode are nucleotide designs
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
       const uint64_t entries = 1ull << (2 * K);
       uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2);
@@ -296,7 +328,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   view_.sa32 = nullptr; view_.isa32 = nullptr; view_.sa40 = nullptr; view_.isa40 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   {
     const bool wide = wide_;                                // rows and text positions no longer fit 32 bits: 5-byte entries
-    const bool possible = h.n >= 64 && h.n < (1ull << 38) && !layout_rb;
+    const bool possible = h.n >= 64 && h.n < (1ull << 38) && !layout_rb && !protein;
     bool want = possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
     if (const char *e = dbg_env("CFR_TEXT_MODE")) want = possible && atoi(e) != 0;
     const size_t esz = wide ? 5 : 4;
@@ -354,6 +386,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     if (const char *e = dbg_env("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;
     for (uint64_t x : h.selected_vals) max_val = std::max(max_val, x);
+    if (protein && h.prot.end_marker_bits > 32) max_val = ~0ull;
     const bool fits32 = h.sampled_bits <= 32 && max_val <= 0xffffffffull;
     uint32_t shift = 0;
     while (shift < 8 && (double)((h.n >> shift) + 1) * 4.0 > budget_gb * 1e9) ++shift;
@@ -525,6 +558,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
   const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
 
+  if (view_.prot.enabled) return launch_search_protein(d_b1, d_o1, d_b2, d_o2, n, total1, total2);
   uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
   uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
   cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
@@ -588,6 +622,31 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   return SearchBuf{hit_off, raw, chain_cnt, cap_total};
 }
 
+// Translated search (Classifier::TranslatedSearch): 6 chains per mate (strand x frame), one lane each
+DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                                          uint64_t total1, uint64_t total2) {
+  const bool paired = d_b2 != nullptr;
+  const size_t nchains = n * (size_t)(paired ? 12 : 6);
+  const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
+  const uint64_t cap_total = 6 * (total1 / 3 / mhl1 + n) + (paired ? 6 * (total2 / 3 / mhl1 + n) : 0);
+  uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
+  uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
+  cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
+  uint32_t *chain_cnt = (uint32_t *)scratch(S_CHAINCNT, nchains * 4);
+  size_t tmp_bytes = scan_tmp_bytes(n);
+  void *tmp = scratch(S_SCAN, tmp_bytes);
+  HIP_CHECK(hipEventRecord(ev_[0], stream_));
+  HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
+  k_caps_prot<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
+  exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
+  HIP_CHECK(hipEventRecord(ev_[1], stream_));
+  if (paired) k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
+  else k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
+  HIP_CHECK(hipGetLastError());
+  HIP_CHECK(hipEventRecord(ev_[2], stream_));
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
+}
+
 void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                               bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st) {
   const bool paired = d_b2 != nullptr;
@@ -606,6 +665,10 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
   HIP_CHECK(hipEventRecord(ev_[8], st));
   HIP_CHECK(hipMemsetAsync(fin_cnt + n, 0, 8, st));
   uint64_t *read_rows = fused ? (uint64_t *)scratch(S_READROWS, (n + 1) * 8) : nullptr;
+  if (view_.prot.enabled) {
+    if (paired) k_select_prot<2><<<grid_for(n), kBlock, 0, st>>>(view_, d_o1, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
+    else k_select_prot<1><<<grid_for(n), kBlock, 0, st>>>(view_, d_o1, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
+  } else
   if (paired) k_adjust_select<4><<<grid_for(n), kBlock, 0, st>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
   else k_adjust_select<2><<<grid_for(n), kBlock, 0, st>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, fin, fin_cnt, fin_rows, read_rows);
   HIP_CHECK(hipGetLastError());
@@ -803,7 +866,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
-  if (dust_ && !src) {
+  if (dust_ && !src && !view_.prot.enabled) {          // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
     // reads already on the device (the caller's buffer stays as it is): mask a private copy
     auto masked_copy = [&](size_t slot, const uint8_t *d_b, const uint64_t *d_o, uint64_t total) -> const uint8_t * {
       uint8_t *c = (uint8_t *)scratch(slot, total + 16);
@@ -820,7 +883,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const size_t nsub = pieces.size();
   const bool paired = d_b2 != nullptr;
   const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;     // k_tail answers rows from the memo itself
-  const bool one_launch = fused && stride > 0 && fused_post_;                   // k_adjust_tail: no host round trip in a piece
+  const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
   std::vector<uint8_t> have_piece(nsub, src ? 0 : 1);
   auto bring_piece = [&](size_t k) {
@@ -832,7 +895,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     };
     one(src->b1, src->o1, d_b1);
     if (paired) one(src->b2, src->o2, d_b2);
-    if (dust_) {       // masked on the copy stream, under the kernels of the previous piece
+    if (dust_ && !view_.prot.enabled) {       // masked on the copy stream, under the kernels of the previous piece
       dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, h2d_stream_);
       if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, h2d_stream_);
     }

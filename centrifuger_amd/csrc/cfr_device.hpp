@@ -48,10 +48,24 @@ struct RbView {
   uint32_t enabled;                  // 0: flat occ image
 };
 
+// Protein image (FMIndex<Sequence_RunBlockOneTree>, sigma = 21): the decoded BWT as five bit planes per 64 symbols plus the
+// per-block symbol counts, so that Rank(c, p) = one count + one 40-byte plane group (two gathers) and Access = the planes.
+struct ProtView {
+  uint32_t enabled, sigma, bits, endmarker_bits;
+  const uint64_t *planes;    // 8 u64 per 64 symbols: plane k = bit k of the plain code of every symbol (5 used)
+  const uint64_t *counts;    // counts[blk * 32 + code] = number of `code` in B[0, 64 blk)
+  const uint64_t *endmarker; // endMarkerSA (FixedSizeElemArray words): the sequence id stored at row i < endmarker_n
+  uint64_t endmarker_n;
+  const uint8_t *code_of;    // 256 entries: character -> plain code, 255 = not in the alphabet
+  uint64_t C[33];            // _plainAlphabetPartialSum
+  char list[32];             // code -> character
+};
+
 struct DevView {            // passed by value to kernels
   uint64_t n, first_isa, adjusted_sa0;
   uint64_t C[5];
   RbView rb;                // run-block image (alternative to occ)
+  ProtView prot;            // protein image (alternative to both)
   const uint64_t *occ;      // 8 u64 per record
   const uint64_t *ftab;     // 2 u64 per entry
   const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l); nullptr = off
@@ -159,6 +173,8 @@ class DeviceIndex {
   struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
   SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                           uint64_t total1, uint64_t total2);
+  SearchBuf launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
+                                  uint64_t total1, uint64_t total2);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                    bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
   std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb) const;
@@ -167,7 +183,7 @@ class DeviceIndex {
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
   void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true);
-  bool one_launch_ready() const { return fused_tail_ && fused_post_ && view_.loc_memo && view_.memo_shift == 0; }
+  bool one_launch_ready() const { return fused_tail_ && fused_post_ && view_.loc_memo && view_.memo_shift == 0 && !view_.prot.enabled; }
 
   const HostIndex *host_;
   int device_;

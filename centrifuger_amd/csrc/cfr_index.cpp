@@ -6,6 +6,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -209,6 +210,151 @@ void parse_fm(const std::string &path, HostIndex &h) {
   check_run_block_lengths(h);
 }
 
+// ---- protein index: FMIndex<Sequence_RunBlockOneTree>::Load (FMIndex.hpp:588-606, Sequence_RunBlockOneTree.hpp:499-513)
+struct GenAlphabet { int32_t method = 0; uint64_t n = 0; char list[256]; int32_t code[256]; int16_t code_len[256]; };
+void parse_gen_alphabet(Cursor &c, GenAlphabet &a) {
+  c.get<uint64_t>();
+  a.method = c.get<int32_t>();
+  a.n = c.get<uint64_t>();
+  if (a.n == 0) return;
+  if (a.n > 64) throw FormatError{"alphabet too large"};
+  c.copy(a.list, a.n);
+  c.copy(a.code, sizeof(a.code));
+  c.copy(a.code_len, sizeof(a.code_len));
+  if (a.method != 1) throw FormatError{"only plain-coded alphabets are supported"};
+}
+struct GenWavelet { uint64_t n = 0; GenAlphabet alphabet; std::vector<int32_t> child0, child1; std::vector<RawBitvector> node; };
+void parse_gen_wavelet(Cursor &c, GenWavelet &w) {
+  c.get<uint64_t>();
+  w.n = c.get<uint64_t>();
+  parse_gen_alphabet(c, w.alphabet);
+  const int32_t node_cnt = c.get<int32_t>();
+  c.get<int32_t>();
+  if (w.alphabet.n == 0) return;
+  if (node_cnt <= 0 || node_cnt > 255) throw FormatError{"unexpected wavelet node count"};
+  w.node.resize((size_t)node_cnt);
+  for (int i = 0; i < node_cnt; ++i) {
+    c.get<uint64_t>();
+    c.get<int32_t>();
+    w.child0.push_back(c.get<int32_t>());
+    w.child1.push_back(c.get<int32_t>());
+    parse_bitvector(c, w.node[(size_t)i]);
+  }
+}
+
+void parse_fm_protein(const std::string &path, HostIndex &h) {
+  Cursor c(path);
+  ProteinPart &P = h.prot;
+  P.enabled = true;
+  h.n = c.get<uint64_t>();
+  h.alphabet_bits = c.get<uint64_t>();
+  h.first_isa = c.get<uint64_t>();
+  h.last_chr = c.get<char>();
+  // Sequence_RunBlockOneTree
+  c.get<uint64_t>();
+  const uint64_t seq_n = c.get<uint64_t>();
+  GenAlphabet seq_alpha;
+  parse_gen_alphabet(c, seq_alpha);
+  h.b = c.get<uint64_t>();
+  h.block_cnt = c.get<uint64_t>();
+  if (seq_n != h.n || h.b == 0 || h.block_cnt != ceil_div(h.n, h.b)) throw FormatError{"inconsistent run-block header"};
+  parse_bitvector(c, h.use_run_block);
+  if (h.use_run_block.n != h.block_cnt) throw FormatError{"useRunBlock length mismatch"};
+  for (uint64_t i = 0; i < seq_alpha.n; ++i) { RawBitvector rb; parse_bitvector(c, rb); }   // _alphabetRB: only Rank needs them; the image is built from the decoded string
+  GenWavelet comp;
+  parse_gen_wavelet(c, comp);
+  GenAlphabet fm_alpha, plain;
+  parse_gen_alphabet(c, fm_alpha);
+  parse_gen_alphabet(c, plain);
+  if (plain.n < 2 || plain.n > 32 || fm_alpha.n != plain.n || h.alphabet_bits == 0 || h.alphabet_bits > 5 || (1ull << h.alphabet_bits) < plain.n)
+    throw FormatError{"unexpected protein alphabet"};
+  P.sigma = (uint32_t)plain.n;
+  P.bits = (uint32_t)h.alphabet_bits;
+  memset(P.code_of, 255, sizeof(P.code_of));
+  for (uint32_t k = 0; k < P.sigma; ++k) {
+    P.list[k] = plain.list[k];
+    if (plain.code[(unsigned char)plain.list[k]] != (int32_t)k) throw FormatError{"plain coder is not the identity on its list"};
+    P.code_of[(unsigned char)plain.list[k]] = (uint8_t)k;
+  }
+  for (uint64_t k = 0; k < fm_alpha.n; ++k) if (P.code_of[(unsigned char)fm_alpha.list[k]] == 255) throw FormatError{"alphabets of the index disagree"};
+  P.C.resize(P.sigma + 1);
+  c.copy(P.C.data(), (P.sigma + 1) * 8);
+  if (P.code_of[(unsigned char)h.last_chr] == 255) throw FormatError{"lastChr not in the alphabet"};
+  h.last_code = P.code_of[(unsigned char)h.last_chr];
+  // _FMIndexAuxData
+  const uint64_t aux_n = c.get<uint64_t>();
+  c.get<int32_t>();
+  h.sample_rate = c.get<int32_t>();
+  h.sample_size = c.get<uint64_t>();
+  h.precompute_width = c.get<uint64_t>();
+  h.precompute_size = c.get<uint64_t>();
+  h.adjusted_sa0 = c.get<uint64_t>();
+  if (aux_n != h.n || h.sample_rate <= 0) throw FormatError{"inconsistent aux header"};
+  if (h.precompute_width * P.bits > 30 || h.precompute_size != (h.precompute_width ? (1ull << (P.bits * h.precompute_width)) : 0))
+    throw FormatError{"unsupported ftab width"};
+  c.get<uint64_t>();
+  h.sampled_bits = c.get<int32_t>();
+  h.sampled_n = c.get<uint64_t>();
+  if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
+  const uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
+  h.sampled_words.assign(sw + 2, 0);
+  c.copy(h.sampled_words.data(), sw * 8);
+  h.ftab.resize(2 * h.precompute_size);
+  c.copy(h.ftab.data(), h.ftab.size() * 8);
+  const uint64_t max_lcp = c.get<uint64_t>();
+  if (max_lcp > 0) c.skip(2 * ceil_div(h.n, 64) * 8);
+  const uint64_t sel_cnt = c.get<uint64_t>();
+  h.selected_filter_rate = c.get<int32_t>();
+  if (sel_cnt != 0) throw FormatError{"protein index with selectedSA rows (the reference never writes those, Builder.hpp:224)"};
+  h.has_end_marker = !c.eof() && c.get<uint8_t>() != 0;
+  if (h.has_end_marker) {
+    c.get<uint64_t>();
+    P.end_marker_bits = c.get<int32_t>();
+    P.end_marker_n = c.get<uint64_t>();
+    if (P.end_marker_bits <= 0 || P.end_marker_bits > 64) throw FormatError{"bad endMarkerSA element width"};
+    const uint64_t ew = ceil_div(P.end_marker_n * (uint64_t)P.end_marker_bits, 64);
+    P.end_marker_words.assign(ew + 2, 0);
+    c.copy(P.end_marker_words.data(), ew * 8);
+  }
+  // ---- decode the BWT (Sequence_RunBlockOneTree::Access for i = 0, 1, ...: the compressed sequence is visited in order, so
+  // every wavelet node is read front to back and no rank is needed)
+  std::vector<uint64_t> cur(comp.node.size(), 0);
+  uint64_t produced = 0;
+  auto next_symbol = [&]() -> uint8_t {
+    if (comp.node.empty()) throw FormatError{"protein index without a compressed sequence"};
+    int ti = 0;
+    uint64_t code = 0;
+    int depth = 0;
+    while (ti != -1) {
+      if (ti < 0 || (size_t)ti >= comp.node.size() || cur[(size_t)ti] >= comp.node[(size_t)ti].n || ++depth > 16) throw FormatError{"wavelet tree walk left the tree"};
+      const unsigned bit = bit_at(comp.node[(size_t)ti], cur[(size_t)ti]++);
+      code = (code << 1) | bit;
+      ti = bit ? comp.child1[(size_t)ti] : comp.child0[(size_t)ti];
+    }
+    ++produced;
+    if (code >= comp.alphabet.n) throw FormatError{"wavelet code outside the alphabet"};
+    const uint8_t k = P.code_of[(unsigned char)comp.alphabet.list[code]];
+    if (k == 255) throw FormatError{"wavelet symbol outside the plain alphabet"};
+    return k;
+  };
+  P.bwt.resize(h.n);
+  for (uint64_t bi = 0; bi < h.block_cnt; ++bi) {
+    const uint64_t lo = bi * h.b, hi = std::min(h.n, lo + h.b);
+    if (bit_at(h.use_run_block, bi)) {
+      const uint8_t k = next_symbol();
+      for (uint64_t i = lo; i < hi; ++i) P.bwt[i] = k;
+    } else {
+      for (uint64_t i = lo; i < hi; ++i) P.bwt[i] = next_symbol();
+    }
+  }
+  if (produced != comp.n) throw FormatError{"run-block component lengths do not add up"};
+  // the partial sums must be those of the decoded string (FMIndex::Init, FMIndex.hpp:335-344)
+  std::vector<uint64_t> cnt(P.sigma + 1, 0);
+  for (uint64_t i = 0; i < h.n; ++i) ++cnt[P.bwt[i] + 1];
+  for (uint32_t k = 1; k <= P.sigma; ++k) cnt[k] += cnt[k - 1];
+  if (cnt != P.C) throw FormatError{"alphabet partial sums do not match the decoded BWT"};
+}
+
 std::string get_string(Cursor &c) {
   uint64_t len = c.get<uint64_t>();
   std::string s(len, '\0');
@@ -277,16 +423,30 @@ bool is_protein(const std::string &prefix) {   // Classifier::IsProteinDatabase 
 }  // namespace
 
 HostIndex *load_index(const std::string &prefix, const cfr_params *params) {
-  if (is_protein(prefix)) throw FormatError{"protein (amino_acid) indexes are out of scope for the MI355X path"};
+  const bool protein = is_protein(prefix);          // Classifier::IsProteinDatabase decides the sequence class (CentrifugerClass.cpp:1001-1004)
   HostIndex *h = new HostIndex();
   try {
-    parse_fm(prefix + ".1.cfr", *h);
+    if (protein) parse_fm_protein(prefix + ".1.cfr", *h);
+    else parse_fm(prefix + ".1.cfr", *h);
     parse_taxonomy(prefix + ".2.cfr", h->tax);
   } catch (...) {
     delete h;
     throw;
   }
   if (params) h->params = *params; else cfr_params_default(&h->params);
+  if (protein) h->score_hit_len_adjust /= 3;         // Classifier.hpp:928-932
+  if (h->params.min_hit_len <= 0 && protein) {
+    // Classifier::InferMinHitLen (Classifier.hpp:113-129) with alphabet size sigma, starting at 11 (Kaiju's default)
+    int m = 11;
+    uint64_t kmerspace = 1;
+    { uint64_t px = h->prot.sigma; int y = m; while (y) { if (y & 1) kmerspace *= px; px *= px; y >>= 1; } }   // Utils::PowerInt
+    kmerspace /= 2;
+    for (; m <= 32; ++m) {
+      if (kmerspace >= 100 * h->n) break;
+      kmerspace *= h->prot.sigma;
+    }
+    h->params.min_hit_len = m;
+  }
   if (h->params.min_hit_len <= 0) {
     // Classifier::InferMinHitLen (Classifier.hpp:113-129): smallest m >= 23 with 4^m / 2 >= 100 n
     int m = 23;

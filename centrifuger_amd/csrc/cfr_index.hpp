@@ -41,6 +41,21 @@ struct Taxonomy {
   uint8_t rank_num[64] = {0};   // Taxonomy::_taxRankNum (Taxonomy.hpp:94-143)
 };
 
+// Protein index (FMIndex<Sequence_RunBlockOneTree>, CentrifugerClass.cpp:1001-1004): the parser checks the components
+// (Sequence_RunBlockOneTree.hpp:499-513) and decodes the BWT once into plain codes; the device builds its occurrence image
+// for the 21-symbol alphabet from those.
+struct ProteinPart {
+  bool enabled = false;
+  uint32_t sigma = 0, bits = 0;          // alphabet size (21: '$' + 20 amino acids), bits per code in the ftab key
+  char list[64] = {0};                   // plain coder: code -> character
+  uint8_t code_of[256];                  // character -> code, 255 = not in the alphabet (Alphabet::IsIn false)
+  std::vector<uint64_t> C;               // sigma + 1 partial sums (_plainAlphabetPartialSum)
+  std::vector<uint8_t> bwt;              // n plain codes
+  std::vector<uint64_t> end_marker_words;   // endMarkerSA (FixedSizeElemArray), rows [0, end_marker_n)
+  int32_t end_marker_bits = 0;
+  uint64_t end_marker_n = 0;
+};
+
 struct HostIndex {
   // FMIndex scalars
   uint64_t n = 0, alphabet_bits = 0, first_isa = 0;
@@ -61,6 +76,7 @@ struct HostIndex {
   int32_t selected_filter_rate = 1024;
   std::vector<uint64_t> selected_rows, selected_vals;   // ascending rows
   bool has_end_marker = false;
+  ProteinPart prot;
   // taxonomy + parameters
   Taxonomy tax;
   cfr_params params;

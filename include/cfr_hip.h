@@ -43,7 +43,7 @@ typedef int cfr_status;
 enum {
   CFR_OK = 0,
   CFR_ERR_IO = 1,          /* cannot open / short read */
-  CFR_ERR_FORMAT = 2,      /* malformed or unsupported .cfr content (e.g. protein index) */
+  CFR_ERR_FORMAT = 2,      /* malformed or unsupported .cfr content */
   CFR_ERR_NO_DEVICE = 3,   /* no HIP device / HIP runtime error at setup */
   CFR_ERR_HIP = 4,         /* HIP runtime error during a batch */
   CFR_ERR_ARG = 5,         /* bad argument */
@@ -96,7 +96,8 @@ typedef struct {
   uint64_t seq_cnt, node_cnt;
   int32_t min_hit_len;         /* after inference */
   char last_chr;
-  char pad[3];
+  uint8_t is_protein;          /* 1: amino-acid index (.4.cfr sequence_type amino_acid): reads are searched translated, never dust-masked */
+  char pad[2];
   uint64_t device_bytes;       /* 0 for a host index */
 } cfr_index_info;
 
