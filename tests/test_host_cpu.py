@@ -57,11 +57,26 @@ def test_open_errors_are_statuses_not_exits(tmp_path):
     with pytest.raises(capi.CfrError) as e:
         capi.Index(str(bad))
     assert e.value.status == capi.CFR_ERR_FORMAT
-    prot = tmp_path / "prot"
+    # a protein prefix (.4.cfr says amino_acid) whose .1.cfr holds a nucleotide index is a format error, not a crash
+    import shutil
+    gold = os.path.join(ROOT, "tests", "golden")
+    for ext in (".1.cfr", ".2.cfr"):
+        shutil.copy(os.path.join(gold, "f6" + ext), tmp_path / ("prot" + ext))
     (tmp_path / "prot.4.cfr").write_text("version\t1\nsequence_type\tamino_acid\n")
     with pytest.raises(capi.CfrError) as e:
-        capi.Index(str(prot))
-    assert e.value.status == capi.CFR_ERR_FORMAT
+        capi.Index(str(tmp_path / "prot"))
+    assert e.value.status in (capi.CFR_ERR_FORMAT, capi.CFR_ERR_IO)
+
+
+def test_protein_index_is_parsed_and_decoded_on_the_host():
+    """FMIndex<Sequence_RunBlockOneTree> files (tests/golden/prot, written by the reference's centrifuger-build --protein):
+    the parser accepts them, says so, and infers min-hitlen like Classifier::InferMinHitLen does for 21 symbols from 11 up."""
+    prot = os.path.join(ROOT, "tests", "golden", "prot")
+    for name in ("p2", "p3_b4", "p2_b1_off2"):
+        info = capi.Index(os.path.join(prot, name)).info()
+        assert info.is_protein == 1 and info.n > 30000 and info.min_hit_len == 11 and info.selected_cnt == 0
+    assert capi.Index(os.path.join(prot, "p2"), capi.default_params(min_hit_len=8)).info().min_hit_len == 8
+    assert capi.Index(os.path.join(ROOT, "tests", "golden", "f6")).info().is_protein == 0
 
 
 def test_device_options_are_validated_before_any_device_work(golden_dir):
