@@ -1,22 +1,43 @@
 #!/bin/bash
 export CFR_DEBUG_ENV=1   # the gate behind which the library reads its CFR_* A/B switches
-# One evidence pass on the GPU box: bench lines (SE with the CPU baseline + parity, PE, long), the kernel trace of the
-# default bench command, and the PMC passes.  usage: tools/evidence.sh <tag>     -> gpurun_out/<tag>_*
+# One evidence pass on the GPU box.  usage: tools/evidence.sh <tag> [big]     -> gpurun_out/<tag>_*
+#   <tag>_bench.json            the default bench line (cfg2 SE + CPU baseline + parity + live PMC roofline + PE / long sub-results)
+#   <tag>_kernel_trace_stats    rocprofv3 --kernel-trace --stats of the same timed steps (no CPU legs)
+#   <tag>_pmc_summary / _pmc_latest.json   per-kernel PMC passes (separate runs per counter group)
+#   <tag>_bench_2ranks.json     bench.py --gpus 2 on this one GPU (CFR_BENCH_SHARE_GPU=1, gloo): the multi-rank code path executed
+#   <tag>_bench_8gbp.json       (with "big") the same bench on an 8 Gbp index: n > 2^32, written on the box by the native writer
 set -u
 TAG=$1
+BIG=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log
-python bench.py --mode pe --no-cpu-baseline > $O/${TAG}_bench_pe.json 2> $O/${TAG}_bench_pe.log
-python bench.py --mode long --no-cpu-baseline > $O/${TAG}_bench_long.json 2> $O/${TAG}_bench_long.log
-# kernel trace of the default command (no CPU baseline leg: it only adds host time)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $ROOT/bench.py --no-cpu-baseline > $O/${TAG}_trace.json 2> $O/${TAG}_trace.log )
+# kernel trace of the timed steps (no CPU baseline leg, no child passes: they only add host time)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $ROOT/bench.py --no-cpu-baseline --no-pmc --no-extra-configs > $O/${TAG}_trace.json 2> $O/${TAG}_trace.log )
 db=$(find $O/${TAG}_trace -name "*.db" | head -1)
 [ -n "$db" ] && python tools/rocpd_summary.py $db $O/${TAG}_kernel_trace_stats.txt
-# PMC passes: one 2 M-read launch per kernel (CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0: a single sub-batch, so per-launch counters divide by 2 M reads)
-CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0 tools/pmc_passes.sh $O/${TAG}_pmc > $O/${TAG}_pmc.log 2>&1
+rm -rf $O/${TAG}_trace
+# PMC passes: one 2 M-read launch per kernel (a single sub-batch, so per-launch counters divide by 2 M reads)
+CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0 tools/pmc_passes.sh $O/${TAG}_pmc --no-pmc --no-extra-configs > $O/${TAG}_pmc.log 2>&1
 python tools/pmc_summary.py $O/${TAG}_pmc > $O/${TAG}_pmc_summary.txt 2>> $O/${TAG}_pmc.log
 python tools/pmc_latest.py $O/${TAG}_pmc $TAG $O/${TAG}_pmc_latest.json >> $O/${TAG}_pmc.log 2>&1
-tail -c 600 $O/${TAG}_bench.json; echo; head -12 $O/${TAG}_kernel_trace_stats.txt; cat $O/${TAG}_pmc_latest.json
+rm -rf $O/${TAG}_pmc/pmc*/
+CFR_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 3 --no-cpu-baseline > $O/${TAG}_bench_2ranks.json 2> $O/${TAG}_bench_2ranks.log
+if [ -n "$BIG" ]; then
+  python bench.py --index-gbp 8 --steps 3 --cpu-sample 500000 > $O/${TAG}_bench_8gbp.json 2> $O/${TAG}_bench_8gbp.log
+fi
+python - <<PY
+import json
+for f in ("bench", "bench_2ranks", "bench_8gbp"):
+    try:
+        d = json.load(open("$O/${TAG}_%s.json" % f))
+    except Exception as e:
+        print(f, "missing:", e); continue
+    r = d.get("roofline", {})
+    print(f, "value %.4g n_gpus %d ms/step %.2f" % (d["value"], d["n_gpus"], d["ms_per_step"]), "roofline.frac", r.get("frac"), "parity", d.get("parity", {}).get("tsv_identical_to_reference"),
+          d.get("parity", {}).get("timed_entry_tsv_identical_to_reference_no_dust"), "dust", d.get("with_device_sdust", {}).get("value"),
+          {k: (v.get("value"), v.get("equals_oracle")) for k, v in d.get("other_configs", {}).items()})
+PY
+head -14 $O/${TAG}_kernel_trace_stats.txt
