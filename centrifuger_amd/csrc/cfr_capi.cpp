@@ -91,7 +91,7 @@ cfr_status cfr_device_index_create_ex(const cfr_index *idx, int device, const cf
   cfr_device_options o;
   cfr_device_options_default(&o);
   if (options) o = *options;
-  if (o.profile != CFR_PROFILE_THROUGHPUT && o.profile != CFR_PROFILE_FAST_LOAD) return bad_arg("cfr_device_index_create_ex: unknown profile");
+  if (o.profile != CFR_PROFILE_THROUGHPUT && o.profile != CFR_PROFILE_FAST_LOAD && o.profile != CFR_PROFILE_BALANCED) return bad_arg("cfr_device_index_create_ex: unknown profile");
   if (o.ftabx_width < -1 || o.ftabx_width > 16) return bad_arg("cfr_device_index_create_ex: ftabx_width out of range");
   return guarded([&]() -> cfr_status {
     cfr::DeviceIndex *d = new cfr::DeviceIndex(*idx->h, device, o);

@@ -8,7 +8,11 @@
 // in input order.  Additive options: --gpu LIST|all, --gpu-batch N, --gpu-throughput.
 // Options of the reference that are outside this build (barcode/UMI/read-format/sample-sheet/
 // merge-readpair/expand-taxid) are rejected with a message instead of being silently ignored.
+#include <fcntl.h>
 #include <getopt.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -51,11 +55,13 @@ const char *kUsage =
     "\t--consider-secondary STR: in the format INT,FLOAT consider the secondary hit if its hitlen>=INT,score>=FLOAT*best_score [2000,0.995]\n"
     "\t--gpu LIST: comma separated MI355X ordinals, or 'all' [0]\n"
     "\t--gpu-batch INT: reads per device batch [262144]\n"
-    "\t--gpu-throughput: build every derived table on the device (longer load, faster classification) [short load]\n"
+    "\t--gpu-balanced: also derive the text-mode tables and the locate memo on the device (+0.4 s load per Gbp, faster kernels)\n"
+    "\t--gpu-throughput: ... and the 68 GB K-mer table (longest load, fastest kernels) [default: neither, shortest load]\n"
+    "\t--parse-threads INT: threads that parse plain single-end read files in pieces [min(-t,4); 1 = sequential reader]\n"
     "\t-h: print this usage message\n"
     "\t-v: print the version information and quit\n";
 
-enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_GPU_THROUGHPUT, OPT_UNSUPPORTED };
+enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_GPU_THROUGHPUT, OPT_GPU_FASTLOAD, OPT_GPU_BALANCED, OPT_PARSE_THREADS, OPT_UNSUPPORTED };
 
 void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp:369-381)
   char buffer[1024];
@@ -69,6 +75,48 @@ void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp
   fprintf(stderr, "[%s] %s\n", stime, buffer);
 }
 
+// Growable byte buffer for the bases of a batch; optionally in PINNED host memory (cfr_host_alloc: the bases then go to the
+// device at PCIe rate, pageable memory is staged by the runtime at a third of that - but pinning 40 MB per batch object costs
+// more than it returns below ~100 M reads, so it is off by default).
+class ByteBuf {
+ public:
+  ByteBuf() = default;
+  ByteBuf(const ByteBuf &) = delete;
+  ByteBuf &operator=(const ByteBuf &) = delete;
+  ~ByteBuf() { release(); }
+  uint8_t *data() { return p_; }
+  const uint8_t *data() const { return p_; }
+  size_t size() const { return n_; }
+  void clear() { n_ = 0; }
+  void reserve(size_t want) {
+    if (want <= cap_) return;
+    size_t cap = cap_ ? cap_ : (1u << 20);
+    while (cap < want) cap *= 2;
+    bool pinned = use_pinned;
+    uint8_t *q = pinned ? (uint8_t *)cfr_host_alloc(cap) : nullptr;
+    if (!q) { pinned = false; q = (uint8_t *)malloc(cap); }
+    if (!q) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
+    if (n_) memcpy(q, p_, n_);
+    release();
+    p_ = q; cap_ = cap; pinned_ = pinned;
+  }
+  void append(const uint8_t *src, size_t len) {
+    if (n_ + len > cap_) { const size_t keep = n_; reserve(n_ + len); n_ = keep; }
+    memcpy(p_ + n_, src, len);
+    n_ += len;
+  }
+  static bool use_pinned;
+ private:
+  void release() {
+    if (p_) { if (pinned_) cfr_host_free(p_); else free(p_); }
+    p_ = nullptr; cap_ = 0;
+  }
+  uint8_t *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+  bool pinned_ = false;
+};
+bool ByteBuf::use_pinned = false;     // measured: hipHostMalloc of 40 MB per batch costs more than the faster copies return (profiles/r2f_cli_timing.txt); CFR_CLI_PIN=1 turns it on
+
 // ---- FASTA/FASTQ (optionally gz) record reader; id = first word of the header -----------------
 // Block reads (16 MB) + memchr line splitting; sequence lines are appended straight into the batch's flat buffers
 // (no per-record strings).  Record grammar as in the reference's kseq use (ReadFiles.hpp:94-160): multi-line FASTA and
@@ -76,11 +124,17 @@ void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp
 class SeqReader {
  public:
   explicit SeqReader(const std::vector<std::string> &files) : files_(files), buf_(1u << 24) {}
+  // a byte range of a memory-mapped plain file that starts at a record header (the parallel path: ParallelFiles below)
+  SeqReader(const char *mem, size_t len) : mem_(mem), pos_(0), end_(len), eof_(true) {}
   ~SeqReader() { if (fp_) gzclose(fp_); }
+
+  // offset (in the memory range) at which the next record starts
+  size_t next_start() const { return have_header_ ? header_off_ : pos_; }
+  bool next_mem(std::vector<char> *ids, ByteBuf &seq, std::vector<char> *qual, bool &has_qual) { return read_record(ids, seq, qual, has_qual); }
 
   // Appends the next record: id (NUL-terminated) to ids, bases to seq, quality to qual when it is wanted.
   // returns false at the end of all files
-  bool next(std::vector<char> *ids, std::vector<uint8_t> &seq, std::vector<char> *qual, bool &has_qual) {
+  bool next(std::vector<char> *ids, ByteBuf &seq, std::vector<char> *qual, bool &has_qual) {
     for (;;) {
       if (!fp_) {
         if (file_idx_ >= files_.size()) return false;
@@ -102,8 +156,9 @@ class SeqReader {
   // next line without its line terminator; the view is valid until the next call.  false: nothing left.
   bool next_line(const char *&p, size_t &n) {
     for (;;) {
-      char *base = buf_.data();
-      if (char *nl = (char *)memchr(base + pos_, '\n', end_ - pos_)) {
+      const char *base = mem_ ? mem_ : buf_.data();
+      line_off_ = pos_;
+      if (const char *nl = (const char *)memchr(base + pos_, '\n', end_ - pos_)) {
         p = base + pos_;
         n = (size_t)(nl - p);
         pos_ = (size_t)(nl - base) + 1;
@@ -118,13 +173,13 @@ class SeqReader {
         while (n && p[n - 1] == '\r') --n;
         return n > 0;
       }
-      if (pos_) { memmove(base, base + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
+      if (pos_) { memmove(buf_.data(), buf_.data() + pos_, end_ - pos_); end_ -= pos_; pos_ = 0; }
       if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
       const int got = gzread(fp_, buf_.data() + end_, (unsigned)std::min<size_t>(buf_.size() - end_, 1u << 30));
       if (got <= 0) eof_ = true; else end_ += (size_t)got;
     }
   }
-  bool read_record(std::vector<char> *ids, std::vector<uint8_t> &seq, std::vector<char> *qual, bool &has_qual) {
+  bool read_record(std::vector<char> *ids, ByteBuf &seq, std::vector<char> *qual, bool &has_qual) {
     const char *p;
     size_t n;
     if (have_header_) { p = header_.data(); n = header_.size(); }
@@ -146,7 +201,7 @@ class SeqReader {
     (void)fastq;
     while (next_line(p, n)) {
       if (n == 0) continue;
-      if (p[0] == '>' || p[0] == '@') { header_.assign(p, n); have_header_ = true; return true; }
+      if (p[0] == '>' || p[0] == '@') { header_.assign(p, n); have_header_ = true; header_off_ = line_off_; return true; }
       if (p[0] == '+') {
         has_qual = true;
         size_t qn = 0;
@@ -157,7 +212,7 @@ class SeqReader {
         } while (qn < seq_n);
         return true;
       }
-      seq.insert(seq.end(), (const uint8_t *)p, (const uint8_t *)p + n);
+      seq.append((const uint8_t *)p, n);
       seq_n += n;
     }
     return true;
@@ -166,10 +221,65 @@ class SeqReader {
   size_t file_idx_ = 0;
   gzFile fp_ = nullptr;
   std::vector<char> buf_;
-  size_t pos_ = 0, end_ = 0;
+  const char *mem_ = nullptr;
+  size_t pos_ = 0, end_ = 0, line_off_ = 0, header_off_ = 0;
   bool eof_ = false;
   std::string header_;
   bool have_header_ = false;
+};
+
+// A plain (not gz) regular read file mapped into memory, and the offsets at which it can be cut into independently parsable
+// pieces.  A cut is a verified record start: FASTA - a line that starts with '>'; FASTQ - a line that starts with '@' whose
+// third line starts with '+' and whose second and fourth lines have the same length (a quality line that starts with '@' fails
+// that: the line two below it is a sequence).  Multi-line FASTQ never verifies; such files take the sequential reader.
+struct MappedFile {
+  const char *base = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  ~MappedFile() { if (base) munmap((void *)base, size); if (fd >= 0) close(fd); }
+  bool open_plain(const std::string &path) {
+    fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 4) return false;
+    size = (size_t)st.st_size;
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) return false;
+    base = (const char *)m;
+    if ((unsigned char)base[0] == 0x1f && (unsigned char)base[1] == 0x8b) return false;      // gz
+    return base[0] == '@' || base[0] == '>';
+  }
+  // first verified record start at or after `from` (a line start), or size
+  size_t resync(size_t from) const {
+    const char fmt = base[0];
+    size_t at = from;
+    if (at > 0 && base[at - 1] != '\n') {
+      const char *nl = (const char *)memchr(base + at, '\n', size - at);
+      if (!nl) return size;
+      at = (size_t)(nl - base) + 1;
+    }
+    auto line_end = [&](size_t a) -> size_t { const char *nl = (const char *)memchr(base + a, '\n', size - a); return nl ? (size_t)(nl - base) : size; };
+    auto trimmed = [&](size_t a, size_t e) -> size_t { while (e > a && base[e - 1] == '\r') --e; return e - a; };
+    while (at < size) {
+      const size_t e0 = line_end(at);
+      if (base[at] == fmt) {
+        if (fmt == '>') return at;
+        const size_t l1 = e0 + 1;
+        if (l1 < size) {
+          const size_t e1 = line_end(l1), l2 = e1 + 1;
+          if (l2 < size && base[l2] == '+') {
+            const size_t e2 = line_end(l2), l3 = e2 + 1;
+            if (l3 <= size) {
+              const size_t e3 = l3 < size ? line_end(l3) : size;
+              if (trimmed(l1, e1) == trimmed(l3, e3) && (e3 + 1 >= size || base[e3 + 1] == '@')) return at;
+            }
+          }
+        }
+      }
+      at = e0 + 1;
+    }
+    return size;
+  }
 };
 
 struct Batch {
@@ -181,7 +291,7 @@ struct Batch {
   std::vector<char> qual1, qual2;      // only filled when reads are dumped (--un / --cl)
   std::vector<size_t> q1_off, q2_off;
   std::vector<uint8_t> has_qual, has_qual2;
-  std::vector<uint8_t> bases1, bases2;
+  ByteBuf bases1, bases2;
   std::vector<uint64_t> offs1, offs2;
   std::vector<cfr_result> results;
   std::vector<cfr_match> matches;
@@ -257,6 +367,8 @@ struct Options {
   bool all_gpus = false;
   size_t gpu_batch = 1u << 18;
   bool throughput_profile = false;
+  int parse_threads = 0;               // 0 = automatic
+  bool balanced_profile = false;
 };
 
 // gz read dumps (ResultWriter::SetOutputReads, ResultWriter.hpp:126-176)
@@ -306,6 +418,8 @@ int main(int argc, char *argv[]) {
       {"min-hitlen", required_argument, 0, OPT_MIN_HITLEN}, {"hitk-factor", required_argument, 0, OPT_HITK},
       {"consider-secondary", required_argument, 0, OPT_SECONDARY}, {"gpu", required_argument, 0, OPT_GPU},
       {"gpu-batch", required_argument, 0, OPT_GPU_BATCH}, {"gpu-throughput", no_argument, 0, OPT_GPU_THROUGHPUT},
+      {"gpu-fast-load", no_argument, 0, OPT_GPU_FASTLOAD}, {"gpu-balanced", no_argument, 0, OPT_GPU_BALANCED},
+      {"parse-threads", required_argument, 0, OPT_PARSE_THREADS},
       {"sample-sheet", required_argument, 0, OPT_UNSUPPORTED}, {"merge-readpair", no_argument, 0, OPT_UNSUPPORTED},
       {"expand-taxid", no_argument, 0, OPT_UNSUPPORTED}, {"read-format", required_argument, 0, OPT_UNSUPPORTED},
       {"barcode", required_argument, 0, OPT_UNSUPPORTED}, {"UMI", required_argument, 0, OPT_UNSUPPORTED},
@@ -347,6 +461,9 @@ int main(int argc, char *argv[]) {
         break;
       case OPT_GPU_BATCH: opt.gpu_batch = strtoull(optarg, nullptr, 10); break;
       case OPT_GPU_THROUGHPUT: opt.throughput_profile = true; break;
+      case OPT_GPU_FASTLOAD: break;                      // the default; accepted for symmetry
+      case OPT_GPU_BALANCED: opt.balanced_profile = true; break;
+      case OPT_PARSE_THREADS: opt.parse_threads = atoi(optarg); break;
       case OPT_UNSUPPORTED:
         print_log("ERROR: option --%s belongs to a part of Centrifuger outside the MI355X classification path and is not available in this build.",
                   long_options[option_index].name);
@@ -374,9 +491,35 @@ int main(int argc, char *argv[]) {
     if (interleaved) r1.reset(new SeqReader(opt.inter));
     else if (paired) { r1.reset(new SeqReader(opt.m1)); r2.reset(new SeqReader(opt.m2)); }
     else r1.reset(new SeqReader(opt.u));
+    ByteBuf::use_pinned = false;
     std::vector<char> ids, q;
-    std::vector<uint8_t> s1, s2;
+    ByteBuf s1, s2;
     bool hq = false, hq2 = false;
+    if (atoi(e) == 3 && !paired) {   // the parallel cutter on every -u file: "cut offsets" then the records piece by piece
+      for (const std::string &f : opt.u) {
+        MappedFile mf;
+        if (!mf.open_plain(f) || mf.resync(0) != 0) { puts("NOT_CUTTABLE"); continue; }
+        const size_t piece = getenv("CFR_CLI_PIECE_BYTES") ? strtoull(getenv("CFR_CLI_PIECE_BYTES"), nullptr, 10) : 64;
+        std::vector<size_t> cuts{0};
+        while (cuts.back() + piece < mf.size) {
+          const size_t c = mf.resync(cuts.back() + piece);
+          if (c >= mf.size || c <= cuts.back()) break;
+          cuts.push_back(c);
+        }
+        cuts.push_back(mf.size);
+        for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+          SeqReader rd(mf.base + cuts[k], cuts[k + 1] - cuts[k]);
+          const size_t span = cuts[k + 1] - cuts[k];
+          for (;;) {
+            ids.clear(); s1.clear(); q.clear();
+            if (!(rd.next_start() < span && rd.next_mem(&ids, s1, &q, hq))) break;
+            printf("%s\t%.*s\t%s%.*s\n", ids.data(), (int)s1.size(), (const char *)s1.data(), hq ? "q:" : "-", (int)q.size(), q.data());
+          }
+          if (rd.next_start() < span) puts("CUT_MISMATCH");
+        }
+      }
+      return 0;
+    }
     if (atoi(e) == 2) {       // count only (parser throughput)
       size_t nrec = 0, nbase = 0;
       const auto tp = tick();
@@ -401,6 +544,12 @@ int main(int argc, char *argv[]) {
     }
     return 0;
   }
+  {   // pinned batch buffers pay off once the input is large (they cost ~0.4 s of allocation per GB of buffers)
+    unsigned long long in_bytes = 0;
+    for (const auto *lst : {&opt.u, &opt.m1, &opt.m2, &opt.inter}) for (const std::string &f : *lst) { struct stat st; if (f != "-" && stat(f.c_str(), &st) == 0) in_bytes += (unsigned long long)st.st_size; }
+    ByteBuf::use_pinned = in_bytes > 20ull << 30;
+  }
+  if (const char *e = getenv("CFR_CLI_PIN")) ByteBuf::use_pinned = atoi(e) != 0;
   StageClock clk;
   const auto t_wall = tick();
   ReadDump un, cl;
@@ -429,16 +578,11 @@ int main(int argc, char *argv[]) {
   const size_t max_inflight = 16;                  // parsed batches waiting (the reader runs ahead of the index load)
 
   std::thread reader([&]() {
-    std::unique_ptr<SeqReader> r1, r2;
     const bool interleaved = !opt.inter.empty();
-    if (interleaved) r1.reset(new SeqReader(opt.inter));
-    else if (paired) { r1.reset(new SeqReader(opt.m1)); r2.reset(new SeqReader(opt.m2)); }
-    else r1.reset(new SeqReader(opt.u));
-    size_t seq_no = 0;
-    bool more = true;
     const bool keep_qual = !opt.un_prefix.empty() || !opt.cl_prefix.empty();
-    while (more) {
-      const auto tp = tick();
+    size_t seq_no = 0;
+    std::atomic<size_t> bases_hint{0};
+    auto fresh_batch = [&]() {
       std::shared_ptr<Batch> b;
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -446,39 +590,128 @@ int main(int argc, char *argv[]) {
       }
       if (!b) b = std::make_shared<Batch>();
       b->reset();
-      b->seq_no = seq_no++;
+      b->bases1.reserve(bases_hint.load());                 // one allocation per batch object instead of a doubling series
+      if (paired) b->bases2.reserve(bases_hint.load());
       b->paired = paired;
       b->offs1.push_back(0);
       if (paired) b->offs2.push_back(0);
-      bool hq = false, hq2 = false;
       b->q1_off.push_back(0);
       b->q2_off.push_back(0);
-      while (b->n < opt.gpu_batch) {
-        const size_t id_at = b->ids.size();
-        if (!r1->next(&b->ids, b->bases1, keep_qual ? &b->qual1 : nullptr, hq)) { more = false; break; }
-        if (paired) {
-          bool ok = interleaved ? r1->next(nullptr, b->bases2, keep_qual ? &b->qual2 : nullptr, hq2)
-                                : r2->next(nullptr, b->bases2, keep_qual ? &b->qual2 : nullptr, hq2);
-          if (!ok) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
-          b->offs2.push_back(b->bases2.size());
-          if (keep_qual) { b->q2_off.push_back(b->qual2.size()); b->has_qual2.push_back(hq2 ? 1 : 0); }
-        }
-        b->id_off.push_back(id_at);
-        b->offs1.push_back(b->bases1.size());
-        if (keep_qual) { b->q1_off.push_back(b->qual1.size()); b->has_qual.push_back(hq ? 1 : 0); }
-        ++b->n;
+      return b;
+    };
+    // one record (+ mate) into b; false at the end of the input
+    auto take = [&](Batch &b, SeqReader *r1, SeqReader *r2, bool from_memory) -> bool {
+      bool hq = false, hq2 = false;
+      const size_t id_at = b.ids.size();
+      const bool ok1 = from_memory ? r1->next_mem(&b.ids, b.bases1, keep_qual ? &b.qual1 : nullptr, hq)
+                                   : r1->next(&b.ids, b.bases1, keep_qual ? &b.qual1 : nullptr, hq);
+      if (!ok1) return false;
+      if (paired) {
+        const bool ok = interleaved ? r1->next(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2)
+                                    : r2->next(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2);
+        if (!ok) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+        b.offs2.push_back(b.bases2.size());
+        if (keep_qual) { b.q2_off.push_back(b.qual2.size()); b.has_qual2.push_back(hq2 ? 1 : 0); }
       }
-      if (!more && paired && !interleaved) {
-        std::vector<uint8_t> extra;
-        if (r2->next(nullptr, extra, nullptr, hq2)) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
-      }
-      clk.add(T_PARSE, tp);
-      if (b->n == 0) break;
+      b.id_off.push_back(id_at);
+      b.offs1.push_back(b.bases1.size());
+      if (keep_qual) { b.q1_off.push_back(b.qual1.size()); b.has_qual.push_back(hq ? 1 : 0); }
+      ++b.n;
+      return true;
+    };
+    auto note_size = [&](const Batch &b) {
+      const size_t want = std::max(b.bases1.size(), b.bases2.size()) + (std::max(b.bases1.size(), b.bases2.size()) >> 3);
+      size_t cur = bases_hint.load();
+      while (want > cur && !bases_hint.compare_exchange_weak(cur, want)) {}
+    };
+    auto publish = [&](const std::shared_ptr<Batch> &b) {
+      note_size(*b);
       std::unique_lock<std::mutex> lk(mu);
       cv.wait(lk, [&]() { return in_order.size() < max_inflight; });
       pending.push_back(b);
       in_order.push_back(b);
       cv.notify_all();
+    };
+    auto read_sequential = [&](SeqReader *r1, SeqReader *r2) {
+      bool more = true;
+      while (more) {
+        const auto tp = tick();
+        std::shared_ptr<Batch> b = fresh_batch();
+        b->seq_no = seq_no++;
+        while (b->n < opt.gpu_batch) if (!take(*b, r1, r2, false)) { more = false; break; }
+        if (!more && paired && !interleaved) {
+          ByteBuf extra;
+          bool hq2 = false;
+          if (r2->next(nullptr, extra, nullptr, hq2)) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+        }
+        clk.add(T_PARSE, tp);
+        if (b->n == 0) break;
+        publish(b);
+      }
+    };
+    // Plain single-end files are cut at verified record starts and parsed by several threads (MappedFile); the pieces are
+    // published in file order.  Anything else (gz, stdin, pairs, files that do not verify) takes the sequential reader.
+    auto read_parallel = [&](const MappedFile &mf, const std::vector<size_t> &cuts) {
+      const size_t nchunks = cuts.size() - 1;
+      std::atomic<size_t> next_chunk{0};
+      size_t publish_next = 0;
+      const int workers = std::max(1, std::min<int>(opt.parse_threads > 0 ? opt.parse_threads : std::min(opt.threads, 4), (int)nchunks));
+      std::vector<std::thread> th;
+      for (int w = 0; w < workers; ++w) th.emplace_back([&]() {
+        std::vector<char> piece;      // the worker's private copy of its piece: pread, not page faults on a mapping every thread shares
+        for (;;) {
+          const size_t k = next_chunk.fetch_add(1);
+          if (k >= nchunks) return;
+          const auto tp = tick();
+          std::shared_ptr<Batch> b = fresh_batch();
+          const size_t span = cuts[k + 1] - cuts[k];
+          if (piece.size() < span) piece.resize(span + (span >> 3));
+          for (size_t got = 0; got < span;) {
+            const ssize_t r = pread(mf.fd, piece.data() + got, span - got, (off_t)(cuts[k] + got));
+            if (r <= 0) { print_log("ERROR: cannot read the read file."); exit(EXIT_FAILURE); }
+            got += (size_t)r;
+          }
+          SeqReader rd(piece.data(), span);
+          while (rd.next_start() < span && take(*b, &rd, nullptr, true)) {}
+          if (rd.next_start() < span) { print_log("ERROR: read file could not be cut at byte %lu; rerun with --parse-threads 1.", (unsigned long)cuts[k + 1]); exit(EXIT_FAILURE); }
+          clk.add(T_PARSE, tp);
+          note_size(*b);
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&]() { return publish_next == k && in_order.size() < max_inflight; });
+          if (b->n) { pending.push_back(b); in_order.push_back(b); }
+          ++publish_next;
+          cv.notify_all();
+        }
+      });
+      for (auto &x : th) x.join();
+      seq_no += nchunks;
+    };
+    if (!paired && opt.parse_threads != 1) {
+      for (const std::string &f : opt.u) {
+        MappedFile mf;
+        std::vector<size_t> cuts;
+        if (f != "-" && mf.open_plain(f) && mf.resync(0) == 0) {
+          // pieces of about one device batch: bytes per record from the first record
+          const size_t second = mf.resync(1);
+          const size_t rec_bytes = std::max<size_t>(16, second);
+          const size_t piece = std::max<size_t>(1u << 16, rec_bytes * opt.gpu_batch);
+          cuts.push_back(0);
+          while (cuts.back() + piece < mf.size) {
+            const size_t c = mf.resync(cuts.back() + piece);
+            if (c >= mf.size || c <= cuts.back()) break;
+            cuts.push_back(c);
+          }
+          cuts.push_back(mf.size);
+        }
+        if (cuts.size() >= 3) read_parallel(mf, cuts);
+        else { SeqReader r1(std::vector<std::string>{f}); read_sequential(&r1, nullptr); }
+      }
+    } else {
+      std::unique_ptr<SeqReader> r1, r2;
+      if (interleaved) r1.reset(new SeqReader(opt.inter));
+      else if (paired) { r1.reset(new SeqReader(opt.m1)); r2.reset(new SeqReader(opt.m2)); }
+      else r1.reset(new SeqReader(opt.u));
+      read_sequential(r1.get(), r2.get());
     }
     std::lock_guard<std::mutex> lk(mu);
     reader_done = true;
@@ -543,7 +776,10 @@ int main(int argc, char *argv[]) {
   t0 = tick();
   cfr_device_options dopt;
   cfr_device_options_default(&dopt);
-  dopt.profile = opt.throughput_profile ? CFR_PROFILE_THROUGHPUT : CFR_PROFILE_FAST_LOAD;   // this program is bound by parsing: prefer a short load
+  // default: the fast-load image.  This program hands the device pageable host buffers, which bounds the device stage at
+  // ~30 M reads/s whatever the tables (profiles/r2f_cli_timing.txt): what a run feels is the load time.  --gpu-balanced adds the
+  // text-mode tables and the locate memo (+0.4 s per Gbp), --gpu-throughput the 68 GB K-mer table as well.
+  dopt.profile = opt.throughput_profile ? CFR_PROFILE_THROUGHPUT : opt.balanced_profile ? CFR_PROFILE_BALANCED : CFR_PROFILE_FAST_LOAD;
   for (int g : opt.gpus) {
     cfr_dev_index *d = nullptr;
     st = cfr_device_index_create_ex(idx, g, &dopt, &d);
@@ -673,5 +909,7 @@ int main(int argc, char *argv[]) {
     for (int k = 0; k < 8; ++k) fprintf(stderr, "[timing] %-12s %8.3f s\n", names[k], (double)clk.ns[k].load() * 1e-9);
   }
   print_log("Centrifuger finishes.");
-  return 0;
+  fflush(stdout);
+  fflush(stderr);
+  _exit(0);       // everything is written; skipping the runtime's teardown saves ~0.3 s of a sub-second run
 }

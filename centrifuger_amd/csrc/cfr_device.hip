@@ -123,7 +123,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   // CFR_PROFILE=fast-load: skip the large derived tables (a command-line run is bound by FASTQ parsing, not by the device;
   // what it feels is the load time).  Default: throughput (all tables).  The specific switches below override either.
   bool fast_load = opt.profile == CFR_PROFILE_FAST_LOAD;
-  if (const char *e = dbg_env("CFR_PROFILE")) fast_load = std::string(e) == "fast-load";
+  bool balanced = opt.profile == CFR_PROFILE_BALANCED;
+  if (const char *e = dbg_env("CFR_PROFILE")) { fast_load = std::string(e) == "fast-load"; balanced = std::string(e) == "balanced"; }
   bool layout_rb = opt.run_block_layout != 0;
   if (const char *e = dbg_env("CFR_LAYOUT")) layout_rb = std::string(e) == "rb";
   memset(&view_.rb, 0, sizeof(view_.rb));
@@ -308,7 +309,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
       while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
-    if (fast_load) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
+    if (fast_load || balanced) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (K > 16) K = 16;

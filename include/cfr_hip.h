@@ -122,10 +122,11 @@ cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_ind
 /* What the device image is built with.  Nothing here changes a result; it trades load time and HBM for throughput.
  * cfr_device_index_create == cfr_device_index_create_ex with the defaults.  (The CFR_* environment variables listed in
  * DESIGN.md section 5 override these fields when set: they exist for A/B runs and for the variant tests.) */
-typedef enum { CFR_PROFILE_THROUGHPUT = 0, CFR_PROFILE_FAST_LOAD = 1 } cfr_profile;
+typedef enum { CFR_PROFILE_THROUGHPUT = 0, CFR_PROFILE_FAST_LOAD = 1, CFR_PROFILE_BALANCED = 2 } cfr_profile;
 typedef struct {
   int32_t profile;        /* cfr_profile.  FAST_LOAD: K-mer table of at most 4^13 entries, no text-mode tables, no locate memo
-                             (load 0.3 s instead of 1.2 s per Gbp; what a parse-bound command line wants) */
+                             (shortest load).  BALANCED: the 4^13 table WITH the text-mode tables and the locate memo (no 68 GB
+                             allocation: what the command line uses).  THROUGHPUT: everything, K up to 16 */
   int32_t ftabx_width;    /* K of the derived K-mer table; -1 = automatic (log4(n)+2, at most 16, a quarter of the free HBM), 0 = none */
   int32_t text_mode;      /* derived SA / ISA / 2-bit text (n < 2^32): -1 = by profile, 0 = off, 1 = on */
   int32_t run_block_layout; /* 1 = keep the run-block components compressed in HBM instead of the flat occurrence image */

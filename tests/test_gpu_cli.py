@@ -51,6 +51,26 @@ def test_cli_several_device_workers_keep_input_order(golden_dir):
     assert out == want
     out = subprocess.run(base + ["--gpu", "all", "--gpu-throughput"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert out == want
+    out = subprocess.run(base + ["--gpu-balanced"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert out == want
+
+
+def test_cli_parallel_reader_of_plain_files(golden_dir, tmp_path):
+    """Plain single-end files are cut at verified record starts and parsed by several threads; rows must come out in file
+    order.  A 64 KB piece size cuts se.fq (400 reads) and a concatenation of it in several pieces; --parse-threads 1 is the
+    sequential reader; both must print the reference's TSV."""
+    want = open(os.path.join(GOLDEN, "tsv", "f6.se_default.tsv"), "rb").read()
+    se = os.path.join(golden_dir, "se.fq")
+    for extra in (["--parse-threads", "4", "--gpu-batch", "50"], ["--parse-threads", "1", "--gpu-batch", "50"], ["--gpu-batch", "60", "-t", "8"]):
+        out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", se] + extra, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert out == want, extra
+    # five copies back to back (ids repeat; the reference would print the same rows five times)
+    big = tmp_path / "big.fq"
+    big.write_bytes(open(se, "rb").read() * 5)
+    rows = want.split(b"\n")[1:-1]
+    out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", str(big), "--parse-threads", "6", "--gpu-batch", "70", "-t", "6"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert out.split(b"\n")[1:-1] == rows * 5
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
@@ -79,7 +99,7 @@ OPTION_SETS = {
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
 @pytest.mark.parametrize("name", sorted(OPTION_SETS))
-@pytest.mark.parametrize("profile", ["fast-load", "throughput"])
+@pytest.mark.parametrize("profile", ["fast-load", "throughput"])       # (fast-load is the command line's default)
 def test_cli_option_corners_against_the_live_reference(name, profile, golden_dir):
     """Option values no committed fixture covers, checked against the reference binary run on the spot (both profiles of the
     command line: the multi-kernel path without derived tables, and the one-launch path with all of them)."""

@@ -299,6 +299,16 @@ def test_cli_read_parser(tmp_path, gz):
                              check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
         want = b"".join(rid + b"\t" + seq + b"\t" + (b"q:" + q if hq else b"-") + b"\n" for rid, seq, q, hq in _py_parse(data))
         assert out == want, name
+        if not gz:
+            # the parallel cutter (plain files only): pieces of ~64 bytes cut at verified record starts give the same records, or
+            # the file is declared not cuttable (multi-line FASTQ, leading blank lines) and the sequential reader takes it
+            par = subprocess.run([cli, "-x", "unused", "-u", str(path)], env=dict(os.environ, CFR_CLI_PARSE_ONLY="3", CFR_CLI_PIECE_BYTES="64"),
+                                 check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            assert b"CUT_MISMATCH" not in par, name
+            if name in ("fastq4", "fasta_multiline_crlf", "fasta_no_trailing_newline", "long_record", "huge_line", "fastq_at_quality"):
+                assert par == want, name
+            else:
+                assert par == want or par.startswith(b"NOT_CUTTABLE"), name
     # pairs: two files and one interleaved file give the same records
     m1 = b"".join(b"@p%d/1\n%s\n+\n%s\n" % (i, dna(40), b"J" * 40) for i in range(50))
     m2 = b"".join(b"@p%d/2\n%s\n+\n%s\n" % (i, dna(45), b"J" * 45) for i in range(50))
