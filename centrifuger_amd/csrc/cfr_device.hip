@@ -307,8 +307,12 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
     uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 2));
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      while (K > view_.ftab_width + 2 && (16ull << (2 * K)) > free_b / 4) --K;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      // the text-mode tables (10.25 bytes per row at 5-byte entries, 8.25 at u32) and a locate memo at every row (4 bytes) are
+      // worth more than the last step of K: the table gets what they leave, and never more than a quarter of the free HBM
+      const double rest = fast_load ? 0.0 : (double)h.n * (h.n >= 0xfffffff0ull ? 14.25 : 12.25) + 8e9;
+      while (K > view_.ftab_width + 2 && ((16ull << (2 * K)) > free_b / 4 || (double)(16ull << (2 * K)) + rest > (double)free_b)) --K;
+    }
     if (fast_load || balanced) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);

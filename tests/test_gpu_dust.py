@@ -113,3 +113,28 @@ def test_classification_with_the_device_pre_step(dev, golden_dir):
     wp_r, wp_m = d.classify(masked, o, masked, o)
     assert gp_r.tobytes() == wp_r.tobytes() and gp_m.tobytes() == wp_m.tobytes()
     assert int((masked != b).sum()) > 1000
+
+
+def _dust_golden():
+    import gzip
+    import oracle_lib as ora
+    from conftest import GOLDEN
+    ids, b, o = ora.read_fastx(os.path.join(GOLDEN, "dust", "reads.fa"))
+    want = {}
+    lines = gzip.open(os.path.join(GOLDEN, "dust", "masked_by_reference.fa.gz"), "rb").read().split(b"\n")
+    for i in range(0, len(lines) - 1, 2):
+        want[lines[i][1:].decode()] = lines[i + 1]
+    return ids, b, o, want
+
+
+def test_device_masks_equal_the_reference_dumps(dev):
+    """1580 adversarial reads (homopolymers around the window size and of 6 kbp, tandem repeats of period 1-13 with 3-8 copies,
+    biased composition, N runs, scattered N, lower case) masked on the device against what the REFERENCE wrote into its
+    --un/--cl dumps for them (tests/golden/dust, made by tests/golden/make_golden_dust.py)."""
+    _, d = dev
+    ids, b, o, want = _dust_golden()
+    got = b.copy()
+    d.dust_mask(got, o)
+    bad = [ids[i] for i in range(len(ids)) if bytes(got[int(o[i]):int(o[i + 1])]) != want[ids[i]]]
+    assert not bad, bad[:10]
+    assert sum(1 for i in range(len(ids)) if bytes(b[int(o[i]):int(o[i + 1])]) != want[ids[i]]) > 500

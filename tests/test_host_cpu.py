@@ -413,3 +413,22 @@ def test_bench_gpus_flag_is_honoured():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and r.stderr.count(b"needs an MI355X") >= 2
+
+
+def test_host_dust_twins_and_oracle_equal_the_reference_dumps():
+    """tests/golden/dust: the masked reads the REFERENCE wrote into its --un/--cl dumps for 1580 adversarial reads; the oracle's
+    SDUST, the bounded host twin and the literal host twin must all reproduce them byte for byte."""
+    import gzip
+    ids, b, o = ora.read_fastx(os.path.join(ROOT, "tests", "golden", "dust", "reads.fa"))
+    lines = gzip.open(os.path.join(ROOT, "tests", "golden", "dust", "masked_by_reference.fa.gz"), "rb").read().split(b"\n")
+    want = {lines[i][1:].decode(): lines[i + 1] for i in range(0, len(lines) - 1, 2)}
+    assert len(want) == len(ids) == 1580
+    for literal in (False, True):
+        got = b.copy()
+        capi.dust_mask(got, o, threads=4, literal=literal)
+        for i, rid in enumerate(ids):
+            assert bytes(got[int(o[i]):int(o[i + 1])]) == want[rid], (rid, literal)
+    for i, rid in enumerate(ids):
+        s = bytes(b[int(o[i]):int(o[i + 1])])
+        if len(s) < 3000:                      # (the oracle's literal list is slow on the 6 kbp homopolymer; the twins cover it)
+            assert ora.dust_mask(s) == want[rid], rid
