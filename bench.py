@@ -55,8 +55,12 @@ def build_index(args, cache, device=None):
         cat = np.concatenate(g.seqs)
     np.save(os.path.join(cache, "genome_cat.npy"), cat)
     lens = np.array([len(s) for s in g.seqs], dtype=np.uint64)
+    if args.index_gbp:      # the writer reads the text once, front to back: hand it the file mapping and let go of the 1 byte/base copy
+        g.seqs = [None] * len(g.seqs)
+        del cat
+        cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     np.save(os.path.join(cache, "genome_starts.npy"), np.concatenate([[0], np.cumsum(lens)]).astype(np.int64))
-    log(f"genomes: {g.total_len/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
+    log(f"genomes: {int(lens.sum())/1e6:.0f} Mbp generated in {time.time()-t0:.1f}s")
     t0 = time.time()
     if args.builder == "own":
         from centrifuger_amd import capi
@@ -429,14 +433,10 @@ def main():
         dist.barrier()
     prefix = os.path.join(cache, "idx")
 
-    t0 = time.time()
     paired = args.mode == "pe"
     k = args.k if args.k is not None else (5 if paired else 1)
-    idx = capi.Index(prefix, capi.default_params(max_result=k))
-    dev = capi.DeviceIndex(idx, local_rank)
-    info = dev.info()
-    log(f"rank {rank}: index n={info.n} b={info.block_size} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
-
+    # reads first, image second: at 40 Gbp the genomes (40 GB, only needed to draw the reads) and the device image (250 GB) do not
+    # fit HBM together
     cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     starts = np.load(os.path.join(cache, "genome_starts.npy"))
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
@@ -455,12 +455,18 @@ def main():
     else:
         reads_d = make_reads_gpu(torch, cat_d, starts, args.reads, args.read_len, args.seed + 1000 + rank, device)
         reads2_d = None
-    del cat_d
+    del cat_d, cat
+    torch.cuda.empty_cache()
     if not longmode:
         offs_d = (torch.arange(args.reads + 1, device=device, dtype=torch.int64) * args.read_len)
     torch.cuda.synchronize()
     offs_h = offs_d.cpu().numpy().astype(np.uint64)
     total_bases = int(offs_h[-1])
+    t0 = time.time()
+    idx = capi.Index(prefix, capi.default_params(max_result=k))
+    dev = capi.DeviceIndex(idx, local_rank)
+    info = dev.info()
+    log(f"rank {rank}: index n={info.n} b={info.block_size} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
 
     def sample_of(t, nsel):
         """first nsel reads of flat device buffer t as (bases, offsets) numpy"""

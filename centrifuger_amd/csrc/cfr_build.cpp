@@ -177,13 +177,13 @@ uint64_t compute_block_size(const uint8_t *S, uint64_t n) {                     
 }
 
 // FixedSizeElemArray layout: element i at bits [i*l, (i+1)*l), LSB first
-std::vector<uint64_t> pack_fixed(const std::vector<uint64_t> &vals, int bits) {
+std::vector<uint64_t> pack_fixed(const std::vector<uint32_t> &vals, int bits) {
   const uint64_t nw = (vals.size() * (uint64_t)bits + 63) / 64;
   std::vector<uint64_t> out(nw + 1, 0);
   for (uint64_t i = 0; i < vals.size(); ++i) {
     const uint64_t pos = i * (uint64_t)bits, wi = pos >> 6, sh = pos & 63;
-    out[wi] |= vals[i] << sh;
-    if (sh + (uint64_t)bits > 64) out[wi + 1] |= vals[i] >> (64 - sh);
+    out[wi] |= (uint64_t)vals[i] << sh;
+    if (sh + (uint64_t)bits > 64) out[wi + 1] |= (uint64_t)vals[i] >> (64 - sh);
   }
   out.resize(nw);
   return out;
@@ -276,29 +276,17 @@ void build_index_files(const BuildInput &in, const BuildOptions &opt, const std:
   const uint64_t n = psum[G];
   int threads = opt.threads > 0 ? opt.threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
 
-  // ---- codes (ACGT only: SequenceCompactor.hpp:59-84 drops everything else before the text is formed; so does the command line)
-  std::vector<uint8_t> codes(n);
-  {
-    uint8_t lut[256];
-    memset(lut, 255, sizeof(lut));
-    for (int i = 0; i < 4; ++i) lut[(unsigned char)kAcgt[i]] = (uint8_t)i;
-    std::vector<std::thread> th;
-    std::vector<int> bad((size_t)threads, 0);
-    for (int t = 0; t < threads; ++t) th.emplace_back([&, t]() {
-      const uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
-      for (uint64_t i = lo; i < hi; ++i) { const uint8_t c = lut[in.text[i]]; if (c > 3) bad[(size_t)t] = 1; codes[i] = c & 3; }
-    });
-    for (auto &x : th) x.join();
-    for (int b : bad) if (b) throw std::runtime_error("index build: the text must be upper-case ACGT only");
-  }
-  const uint8_t last_code = codes[n - 1];
+  // (the text must be upper-case ACGT only - SequenceCompactor.hpp:59-84 drops everything else before the text is formed, so does
+  // the command line; the device checks it while packing the text, no host copy is made)
+  const char *lp = strchr(kAcgt, (char)in.text[n - 1]);
+  if (!lp || !in.text[n - 1]) throw std::runtime_error("index build: the text must be upper-case ACGT only");
+  const uint8_t last_code = (uint8_t)(lp - kAcgt);
 
   // ---- suffix array and what is read off it (device)
   std::vector<uint64_t> want;              // selectedSA: the row of text position psum[g+1] - w - 1 for every genome boundary (Builder.hpp:224-234)
   for (size_t g = 0; g + 1 < G; ++g) if (psum[g + 1] >= (uint64_t)w + 1) want.push_back(psum[g + 1] - w - 1);
   SaProducts sa;
-  build_sa_products(codes.data(), n, opt.device, rate, w, psum, want, sa, say);
-  { std::vector<uint8_t>().swap(codes); }
+  build_sa_products(in.text, n, opt.device, rate, w, psum, want, sa, say);
   say("suffix array + products: " + std::to_string(sa.seconds_sa) + " + " + std::to_string(sa.seconds_products) + " s");
   std::map<uint64_t, uint64_t> sel;
   for (size_t k = 0; k < want.size(); ++k) {

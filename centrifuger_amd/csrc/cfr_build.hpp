@@ -18,16 +18,16 @@ namespace cfr {
 struct SaProducts {
   uint64_t n = 0, first_isa = 0;
   std::vector<uint8_t> bwt;              // n codes 0..3: B[i] = T[SA[i]-1], T[n-1] at the row of position 0 (FMBuilder.hpp:244-250)
-  std::vector<uint64_t> sampled_ids;     // sequence id of SA[k * rate] with the fuzzy boundary (Builder.hpp:27-51)
+  std::vector<uint32_t> sampled_ids;     // sequence id of SA[k * rate] with the fuzzy boundary (Builder.hpp:27-51)
   std::vector<uint64_t> rows_of;         // rows of the requested text positions (for selectedSA, Builder.hpp:224-234)
   std::vector<uint64_t> ftab;            // 4^w pairs (first row, count) over suffixes of >= w characters (FMBuilder.hpp:256-283)
   double seconds_sa = 0, seconds_products = 0;
   int rounds = 0;
 };
 
-// codes: n symbols 0..3 (host).  psum: G+1 sequence start offsets.  want_pos: text positions whose rows are wanted.
-// Throws HipError (cfr_device.hpp) on device failure / unsupported size.
-void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sample_rate, uint32_t ftab_width,
+// text: n upper-case A,C,G,T (host; read once, front to back).  psum: G+1 sequence start offsets.  want_pos: text positions
+// whose rows are wanted.  Throws HipError (cfr_device.hpp) on device failure / unsupported size / other characters.
+void build_sa_products(const uint8_t *text, uint64_t n, int device, uint32_t sample_rate, uint32_t ftab_width,
                        const std::vector<uint64_t> &psum, const std::vector<uint64_t> &want_pos, SaProducts &out,
                        const std::function<void(const std::string &)> &log);
 

@@ -15,16 +15,21 @@
 //             in-place rank refinement between spans is the one Larsson-Sadakane rely on.
 //   A suffix shorter than the comparison depth is padded with symbol 0; among the members of one group the padded ones
 //   come first, shortest first (key n-1-pos < h <= every in-range key RANK + h): a proper prefix sorts first.
-// Memory: 10.4 bytes per symbol + ~13 GB of chunk buffers: 8 Gbp = 96 GB, 16 Gbp = 180 GB (n < 2^34 in this form).
+// Memory: 10.4 bytes per symbol + ~15 GB of chunk buffers: 8 Gbp = 98 GB, 16 Gbp = 182 GB.  Texts whose SA + RANK do not fit
+// (above ~24 Gbp on a 288 GB device) keep the SA in HOST memory: RANK, text and head bits stay in HBM (5.4 bytes per symbol),
+// a phase-1 chunk is copied out once it is committed and a phase-2 span is copied in, refined and copied back only when it
+// still holds unresolved groups.  The composite key (group offset : second key) is 64 bits wide for n + 2^27 < 2^36.
 #include "cfr_build.hpp"
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 
 #include "cfr_device.hpp"      // HipError
 
@@ -47,17 +52,22 @@ __device__ __forceinline__ uint64_t get40(const uint8_t *tab, uint64_t i) {
 }
 
 constexpr uint32_t kBinBits = 14;                 // phase-1 chunks are unions of 14-bit key prefixes
-constexpr uint64_t kChunk = 1ull << 28;           // rows per sort
-constexpr uint32_t kRankBits = 35;                // composite key = group offset in the span (28 bits) : second key (35 bits)
+constexpr uint64_t kChunkDefault = 1ull << 28;    // rows per sort
+// composite key of phase 2 = group offset in the span (<= 28 bits, top) : second key (rank_bits = bits of n + 2^27, low)
 
 // ---- text ------------------------------------------------------------------------------------------------------------
-// codes (one byte per symbol, a piece of the text starting at a multiple of 32) -> packed words
-__global__ void k_pack_text(const uint8_t *codes, uint64_t count, uint64_t *words) {
+// ASCII text (a piece starting at a multiple of 32) -> packed words; *bad is raised when a character is not an upper-case A,C,G,T
+__global__ void k_pack_text(const uint8_t *text, uint64_t count, uint64_t *words, unsigned int *bad) {
   const uint64_t wI = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (wI * 32 >= count) return;
   uint64_t w = 0;
   const uint64_t base = wI * 32;
-  for (uint32_t k = 0; k < 32 && base + k < count; ++k) w |= (uint64_t)(codes[base + k] & 3u) << (62 - 2 * k);
+  for (uint32_t k = 0; k < 32 && base + k < count; ++k) {
+    const uint32_t ch = text[base + k];
+    const uint32_t c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+    if (c > 3u) *bad = 1u;
+    w |= (uint64_t)(c & 3u) << (62 - 2 * k);
+  }
   words[wI] = w;
 }
 __device__ __forceinline__ uint64_t key32(const uint64_t *T, uint64_t pos) {
@@ -135,13 +145,14 @@ __global__ void k_new_heads(const uint64_t *K, uint64_t m, const uint64_t *slots
   headslot[a] = isnew ? (slots ? slots[a] : slot_base + a) + 1 : 0;        // +1: slot 0 must beat "not a head"
 }
 struct MaxOp { __host__ __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; } };
+// sa holds the rows from sa_off on (the whole array with sa_off = 0, or the buffer of one chunk / span when the SA lives on the host)
 __global__ void k_commit(const uint64_t *P, const uint64_t *grp, const uint64_t *headslot_raw, uint64_t m, const uint64_t *slots, uint64_t slot_base,
-                         uint8_t *sa, uint8_t *rank, unsigned long long *head_bits) {
+                         uint8_t *sa, uint64_t sa_off, uint8_t *rank, unsigned long long *head_bits) {
   const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
   const uint64_t slot = slots ? slots[a] : slot_base + a;
   const uint64_t pos = P[a];
-  put40(sa, slot, pos);
+  put40(sa, slot - sa_off, pos);
   put40(rank, pos, grp[a] - 1);
   if (headslot_raw[a]) atomicOr(head_bits + (slot >> 6), 1ull << (slot & 63));
 }
@@ -165,31 +176,33 @@ __global__ void k_active_heads(const unsigned long long *hb, const uint64_t *slo
   const uint64_t j = slots[a];
   headslot[a] = head_bit(hb, j) ? j + 1 : 0;
 }
-__global__ void k_gather_keys(const uint8_t *sa, const uint8_t *rank, const uint64_t *slots, const uint64_t *grp, uint64_t m, uint64_t span_lo,
-                              uint64_t n, uint64_t h, uint64_t *K, uint64_t *P) {
+__global__ void k_gather_keys(const uint8_t *sa, uint64_t sa_off, const uint8_t *rank, const uint64_t *slots, const uint64_t *grp, uint64_t m, uint64_t span_lo,
+                              uint64_t n, uint64_t h, uint32_t rank_bits, uint64_t *K, uint64_t *P) {
   const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= m) return;
-  const uint64_t pos = get40(sa, slots[a]);
+  const uint64_t pos = get40(sa, slots[a] - sa_off);
   const uint64_t k2 = pos + h >= n ? n - 1 - pos : get40(rank, pos + h) + h;
-  K[a] = ((grp[a] - 1 - span_lo) << kRankBits) | k2;
+  K[a] = ((grp[a] - 1 - span_lo) << rank_bits) | k2;
   P[a] = pos;
 }
 
 // ---- products --------------------------------------------------------------------------------------------------------
-__global__ void k_bwt(const uint64_t *T, const uint8_t *sa, uint64_t n, uint8_t *bwt, unsigned long long *first_isa) {
-  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t pos = get40(sa, j);
-    if (pos == 0) { *first_isa = j; bwt[j] = (uint8_t)sym_at(T, n - 1); }
-    else bwt[j] = (uint8_t)sym_at(T, pos - 1);
+// the products below work on the rows [lo, hi) whose SA entries sit in sa from sa_off on
+__global__ void k_bwt(const uint64_t *T, const uint8_t *sa, uint64_t sa_off, uint64_t lo, uint64_t hi, uint64_t n, uint8_t *bwt, unsigned long long *first_isa) {
+  for (uint64_t j = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < hi; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t pos = get40(sa, j - sa_off);
+    if (pos == 0) { *first_isa = j; bwt[j - lo] = (uint8_t)sym_at(T, n - 1); }
+    else bwt[j - lo] = (uint8_t)sym_at(T, pos - 1);
   }
 }
-__global__ void k_sampled(const uint8_t *sa, uint64_t n, uint32_t rate, uint32_t w, const uint64_t *psum, uint64_t nseq, uint64_t cnt, uint32_t *ids) {
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t pos = get40(sa, k * rate);
+// samples k_lo .. k_hi (row k * rate each) -> ids[k - k_lo]
+__global__ void k_sampled(const uint8_t *sa, uint64_t sa_off, uint64_t n, uint32_t rate, uint32_t w, const uint64_t *psum, uint64_t nseq, uint64_t k_lo, uint64_t k_hi, uint32_t *ids) {
+  for (uint64_t k = k_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < k_hi; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t pos = get40(sa, k * rate - sa_off);
     const uint64_t adj = pos + w + 1 < n ? pos + w + 1 : pos;       // the fuzzy boundary of Builder.hpp:27-51
     uint64_t lo = 0, hi = nseq + 1;                                  // upper_bound(psum, adj) - 1
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (psum[mid] <= adj) lo = mid + 1; else hi = mid; }
-    ids[k] = (uint32_t)(lo - 1);
+    ids[k - k_lo] = (uint32_t)(lo - 1);
   }
 }
 __global__ void k_rows_of(const uint8_t *rank, const uint64_t *want, uint64_t cnt, uint64_t *rows) {
@@ -198,13 +211,14 @@ __global__ void k_rows_of(const uint8_t *rank, const uint64_t *want, uint64_t cn
 }
 // ftab: rows are in suffix order, so equal w-mers are contiguous among the rows that have w characters.  One lane walks
 // 256 rows and flushes a (key, first row, count) run at every key change.
-__global__ void k_ftab(const uint64_t *T, const uint8_t *sa, uint64_t n, uint32_t w, unsigned long long *first, unsigned long long *count) {
+__global__ void k_ftab(const uint64_t *T, const uint8_t *sa, uint64_t sa_off, uint64_t row_lo, uint64_t row_hi, uint64_t n, uint32_t w,
+                       unsigned long long *first, unsigned long long *count) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t lo = t * 256, hi = lo + 256 < n ? lo + 256 : n;
-  if (lo >= n) return;
+  const uint64_t lo = row_lo + t * 256, hi = lo + 256 < row_hi ? lo + 256 : row_hi;
+  if (lo >= row_hi) return;
   uint64_t cur = ~0ull, cur_first = 0, cur_cnt = 0;
   for (uint64_t j = lo; j < hi; ++j) {
-    const uint64_t pos = get40(sa, j);
+    const uint64_t pos = get40(sa, j - sa_off);
     if (pos + w > n) continue;
     uint64_t k = key32(T, pos) >> (64 - 2 * w);                     // first symbol in the top pair ...
     uint64_t r = __brevll(k) >> (64 - 2 * w);                       // ... PackRead wants it in the lowest (FMBuilder.hpp:256-283)
@@ -240,14 +254,14 @@ inline unsigned grid_of(uint64_t n, unsigned block = 256) { return (unsigned)std
 
 }  // namespace
 
-void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sample_rate, uint32_t w,
+void build_sa_products(const uint8_t *text, uint64_t n, int device, uint32_t sample_rate, uint32_t w,
                        const std::vector<uint64_t> &psum, const std::vector<uint64_t> &want_pos, SaProducts &out,
                        const std::function<void(const std::string &)> &log) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"index build: no HIP device (the writer has no CPU path)", -1};
   if (device < 0 || device >= count) throw HipError{"index build: device ordinal out of range", -1};
   if (n < 64) throw HipError{"index build: text shorter than 64 symbols", -2};
-  if (n >= (1ull << 34) - (1ull << 28)) throw HipError{"index build: texts of 2^34 symbols and more are beyond this single-GPU writer", -2};
+  if (n + (1ull << 27) >= (1ull << 36)) throw HipError{"index build: texts of 2^36 symbols and more are beyond this single-GPU writer", -2};
   if (w < 1 || w > 16) throw HipError{"index build: ftab width must be in 1..16", -2};
   BCHECK(hipSetDevice(device));
   hipStream_t st = nullptr;      // default stream: everything here is sequential
@@ -263,17 +277,41 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
   BCHECK(hipMemsetAsync(T, 0, (nwords + 4) * 8, st));
   {
     const uint64_t piece = 1ull << 30;
-    DevBuf stage(piece);
+    DevBuf stage(piece), d_bad(4);
+    BCHECK(hipMemsetAsync(d_bad.p, 0, 4, st));
     for (uint64_t lo = 0; lo < n; lo += piece) {
       const uint64_t cnt = std::min(piece, n - lo);
-      BCHECK(hipMemcpy(stage.p, codes + lo, cnt, hipMemcpyHostToDevice));
-      k_pack_text<<<grid_of((cnt + 31) / 32), 256, 0, st>>>(stage.as<uint8_t>(), cnt, T + lo / 32);
+      BCHECK(hipMemcpy(stage.p, text + lo, cnt, hipMemcpyHostToDevice));
+      k_pack_text<<<grid_of((cnt + 31) / 32), 256, 0, st>>>(stage.as<uint8_t>(), cnt, T + lo / 32, d_bad.as<unsigned int>());
       BCHECK(hipGetLastError());
       BCHECK(hipStreamSynchronize(st));
     }
+    unsigned int bad = 0;
+    BCHECK(hipMemcpy(&bad, d_bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) throw HipError{"index build: the text must be upper-case ACGT only", -2};
   }
 
-  DevBuf d_sa(n * 5 + 16), d_rank(n * 5 + 16), d_head(((n + 1 + 63) / 64 + 2) * 8);
+  uint32_t rank_bits = 1;
+  while ((n + (1ull << 27)) >> rank_bits) ++rank_bits;
+  // test hooks (behind the CFR_DEBUG_ENV gate, like the classifier's switches): a small chunk makes small texts take many
+  // chunks and spans; CFR_BUILD_HOST_SA forces the host-resident suffix array
+  const bool dbg = getenv("CFR_DEBUG_ENV") && atoi(getenv("CFR_DEBUG_ENV"));
+  uint64_t kChunk = kChunkDefault;
+  if (dbg && getenv("CFR_BUILD_CHUNK_LOG2")) kChunk = 1ull << std::min(28, std::max(12, atoi(getenv("CFR_BUILD_CHUNK_LOG2"))));
+  const uint64_t kMargin = std::min<uint64_t>(1ull << 20, kChunk / 2);      // a span ends on the first group boundary past chunk - margin
+  // SA on the device when SA + RANK + text + head bits + chunk buffers fit, else in host memory (one chunk / span on the device)
+  size_t free_b = 0, total_b = 0;
+  BCHECK(hipMemGetInfo(&free_b, &total_b));
+  const bool host_sa = (double)n * 10.2 + 16e9 > 0.95 * (double)free_b || (dbg && getenv("CFR_BUILD_HOST_SA") && atoi(getenv("CFR_BUILD_HOST_SA")));
+  if (host_sa && (double)n * 5.2 + 22e9 > 0.95 * (double)free_b) throw HipError{"index build: the text does not fit this device even with the suffix array on the host", -3};
+  std::unique_ptr<uint8_t[]> hsa_mem;       // (not a vector: 5 n bytes must not be zero-filled first)
+  uint8_t *hsa = nullptr;
+  if (host_sa) {
+    hsa_mem.reset(new uint8_t[n * 5 + 16]);
+    hsa = hsa_mem.get();
+    if (log) log("suffix array kept in host memory (" + std::to_string((n * 5) >> 30) + " GiB); RANK, text and head bits in HBM");
+  }
+  DevBuf d_sa(host_sa ? kChunk * 5 + 16 : n * 5 + 16), d_rank(n * 5 + 16), d_head(((n + 1 + 63) / 64 + 2) * 8);
   uint8_t *SA = d_sa.as<uint8_t>(), *RANK = d_rank.as<uint8_t>();
   unsigned long long *HB = d_head.as<unsigned long long>();
   BCHECK(hipMemsetAsync(HB, 0, ((n + 1 + 63) / 64 + 2) * 8, st));
@@ -293,11 +331,12 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
   const size_t tmp_bytes = std::max(tmp_sort, std::max(tmp_scan, tmp_sel));
   DevBuf bTmp(tmp_bytes);
 
-  auto commit = [&](uint64_t *Ksorted, uint64_t *Psorted, uint64_t m, const uint64_t *slots, uint64_t slot_base) {
+  // sa_off: first row the SA buffer holds (0 with the whole array on the device)
+  auto commit = [&](uint64_t *Ksorted, uint64_t *Psorted, uint64_t m, const uint64_t *slots, uint64_t slot_base, uint64_t sa_off) {
     k_new_heads<<<grid_of(m), 256, 0, st>>>(Ksorted, m, slots, slot_base, HS);
     size_t tb = tmp_bytes;
     BCHECK(hipcub::DeviceScan::InclusiveScan(bTmp.p, tb, HS, GRP, MaxOp(), m, st));
-    k_commit<<<grid_of(m), 256, 0, st>>>(Psorted, GRP, HS, m, slots, slot_base, SA, RANK, HB);
+    k_commit<<<grid_of(m), 256, 0, st>>>(Psorted, GRP, HS, m, slots, slot_base, SA, sa_off, RANK, HB);
     BCHECK(hipGetLastError());
   };
 
@@ -316,14 +355,15 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
       uint32_t hi = bin;
       uint64_t cnt = 0;
       while (hi < (1u << kBinBits) && cnt + hist[hi] <= kChunk) cnt += hist[hi++];
-      if (hi == bin) throw HipError{"index build: more than 2^28 suffixes share one 7-symbol prefix (text too skewed for this writer)", -2};
+      if (hi == bin) throw HipError{"index build: more suffixes than one chunk holds share one 7-symbol prefix (text too skewed for this writer)", -2};
       if (cnt) {
         BCHECK(hipMemsetAsync(d_scalar, 0, 8, st));
         k_collect<<<4096, 256, 0, st>>>(T, n, bin, hi, d_scalar, K0, P0);
         BCHECK(hipGetLastError());
         size_t tb = tmp_bytes;
         BCHECK(hipcub::DeviceRadixSort::SortPairs(bTmp.p, tb, K0, K1, P0, P1, cnt, 0, 64, st));
-        commit(K1, P1, cnt, nullptr, base);
+        commit(K1, P1, cnt, nullptr, base, host_sa ? base : 0);
+        if (host_sa) BCHECK(hipMemcpy(hsa + base * 5, SA, cnt * 5, hipMemcpyDeviceToHost));
         ++chunks;
       }
       base += cnt;
@@ -348,8 +388,8 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
     uint64_t lo = 0;
     while (lo < n) {
       uint64_t hi = n;
-      if (n - lo > kChunk - (1ull << 20)) {      // a span ends on the first group boundary at or after lo + 2^28 - 2^20 (groups are far smaller than 2^20)
-        k_next_head<<<1, 1, 0, st>>>(HB, lo + kChunk - (1ull << 20), (uint64_t *)d_scalar + 1);
+      if (n - lo > kChunk - kMargin) {      // a span ends on the first group boundary at or after lo + chunk - margin (groups are far smaller than the margin)
+        k_next_head<<<1, 1, 0, st>>>(HB, lo + kChunk - kMargin, (uint64_t *)d_scalar + 1);
         BCHECK(hipMemcpy(&hi, (uint64_t *)d_scalar + 1, 8, hipMemcpyDeviceToHost));
         if (hi - lo > kChunk) throw HipError{"index build: a group of more than 2^20 equal prefixes (text too repetitive for this writer)", -2};
       }
@@ -359,14 +399,16 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
       uint64_t m = 0;
       BCHECK(hipMemcpy(&m, d_scalar, 8, hipMemcpyDeviceToHost));
       if (m) {
+        if (host_sa) BCHECK(hipMemcpy(SA, hsa + lo * 5, (hi - lo) * 5, hipMemcpyHostToDevice));
         k_active_heads<<<grid_of(m), 256, 0, st>>>(HB, SL, m, HS);
         tb = tmp_bytes;
         BCHECK(hipcub::DeviceScan::InclusiveScan(bTmp.p, tb, HS, GRP, MaxOp(), m, st));
-        k_gather_keys<<<grid_of(m), 256, 0, st>>>(SA, RANK, SL, GRP, m, lo, n, h, K0, P0);
+        k_gather_keys<<<grid_of(m), 256, 0, st>>>(SA, host_sa ? lo : 0, RANK, SL, GRP, m, lo, n, h, rank_bits, K0, P0);
         BCHECK(hipGetLastError());
         tb = tmp_bytes;
         BCHECK(hipcub::DeviceRadixSort::SortPairs(bTmp.p, tb, K0, K1, P0, P1, m, 0, 64, st));
-        commit(K1, P1, m, SL, 0);
+        commit(K1, P1, m, SL, 0, host_sa ? lo : 0);
+        if (host_sa) BCHECK(hipMemcpy(hsa + lo * 5, SA, (hi - lo) * 5, hipMemcpyDeviceToHost));
       }
       active_total += m;
       lo = hi;
@@ -396,32 +438,40 @@ void build_sa_products(const uint8_t *codes, uint64_t n, int device, uint32_t sa
   d_rank.release();
   d_head.release();
   {
-    const uint64_t cnt = (n + sample_rate - 1) / sample_rate;
-    DevBuf d_psum(psum.size() * 8), d_ids(cnt * 4);
+    // rows in pieces: the whole array when the SA is on the device, one chunk at a time from the host copy otherwise
+    const uint64_t piece = host_sa ? kChunk : n;
+    const uint64_t nsamp = (n + sample_rate - 1) / sample_rate, entries = 1ull << (2 * w);
+    DevBuf d_psum(psum.size() * 8), d_ids(std::min<uint64_t>(nsamp, piece / sample_rate + 2) * 4), d_first(entries * 8), d_count(entries * 8), d_ftab(entries * 16);
+    DevBuf d_bwt(piece), d_fi(8);
     BCHECK(hipMemcpy(d_psum.p, psum.data(), psum.size() * 8, hipMemcpyHostToDevice));
-    k_sampled<<<(unsigned)std::min<uint64_t>(grid_of(cnt), 1u << 20), 256, 0, st>>>(SA, n, sample_rate, w, d_psum.as<uint64_t>(), psum.size() - 1, cnt, d_ids.as<uint32_t>());
-    BCHECK(hipGetLastError());
-    std::vector<uint32_t> ids(cnt);
-    BCHECK(hipMemcpy(ids.data(), d_ids.p, cnt * 4, hipMemcpyDeviceToHost));
-    out.sampled_ids.assign(ids.begin(), ids.end());
-  }
-  {
-    const uint64_t entries = 1ull << (2 * w);
-    DevBuf d_first(entries * 8), d_count(entries * 8), d_ftab(entries * 16);
     BCHECK(hipMemsetAsync(d_first.p, 0xff, entries * 8, st));
     BCHECK(hipMemsetAsync(d_count.p, 0, entries * 8, st));
-    k_ftab<<<grid_of((n + 255) / 256), 256, 0, st>>>(T, SA, n, w, d_first.as<unsigned long long>(), d_count.as<unsigned long long>());
+    BCHECK(hipMemsetAsync(d_fi.p, 0, 8, st));
+    out.bwt.resize(n);
+    std::vector<uint32_t> &ids = out.sampled_ids;
+    ids.resize(nsamp);
+    for (uint64_t lo = 0; lo < n; lo += piece) {
+      const uint64_t hi = std::min(n, lo + piece), sa_off = host_sa ? lo : 0;
+      if (host_sa) BCHECK(hipMemcpy(SA, hsa + lo * 5, (hi - lo) * 5, hipMemcpyHostToDevice));
+      const uint64_t k_lo = (lo + sample_rate - 1) / sample_rate, k_hi = (hi + sample_rate - 1) / sample_rate;      // samples with row in [lo, hi)
+      if (k_hi > k_lo) {
+        k_sampled<<<(unsigned)std::min<uint64_t>(grid_of(k_hi - k_lo), 1u << 20), 256, 0, st>>>(SA, sa_off, n, sample_rate, w, d_psum.as<uint64_t>(), psum.size() - 1, k_lo, k_hi, d_ids.as<uint32_t>());
+        BCHECK(hipGetLastError());
+        BCHECK(hipMemcpy(ids.data() + k_lo, d_ids.p, (k_hi - k_lo) * 4, hipMemcpyDeviceToHost));
+      }
+      k_ftab<<<grid_of((hi - lo + 255) / 256), 256, 0, st>>>(T, SA, sa_off, lo, hi, n, w, d_first.as<unsigned long long>(), d_count.as<unsigned long long>());
+      k_bwt<<<(unsigned)std::min<uint64_t>(grid_of(hi - lo), 1u << 20), 256, 0, st>>>(T, SA, sa_off, lo, hi, n, d_bwt.as<uint8_t>(), d_fi.as<unsigned long long>());
+      BCHECK(hipGetLastError());
+      BCHECK(hipMemcpy(out.bwt.data() + lo, d_bwt.p, hi - lo, hipMemcpyDeviceToHost));
+      if (host_sa) {      // this piece of the host copy is done with: give its pages back while the BWT grows
+        const uintptr_t a0 = ((uintptr_t)(hsa + lo * 5) + 4095) & ~(uintptr_t)4095, a1 = (uintptr_t)(hsa + hi * 5) & ~(uintptr_t)4095;
+        if (a1 > a0) (void)madvise((void *)a0, a1 - a0, MADV_DONTNEED);
+      }
+    }
     k_ftab_finish<<<grid_of(entries), 256, 0, st>>>(entries, d_first.as<unsigned long long>(), d_count.as<unsigned long long>(), d_ftab.as<uint64_t>());
     BCHECK(hipGetLastError());
     out.ftab.resize(entries * 2);
     BCHECK(hipMemcpy(out.ftab.data(), d_ftab.p, entries * 16, hipMemcpyDeviceToHost));
-  }
-  {
-    DevBuf d_bwt(n), d_fi(8);
-    k_bwt<<<(unsigned)std::min<uint64_t>(grid_of(n), 1u << 20), 256, 0, st>>>(T, SA, n, d_bwt.as<uint8_t>(), d_fi.as<unsigned long long>());
-    BCHECK(hipGetLastError());
-    out.bwt.resize(n);
-    BCHECK(hipMemcpy(out.bwt.data(), d_bwt.p, n, hipMemcpyDeviceToHost));
     unsigned long long fi = 0;
     BCHECK(hipMemcpy(&fi, d_fi.p, 8, hipMemcpyDeviceToHost));
     out.first_isa = fi;

@@ -310,7 +310,9 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       // the text-mode tables (10.25 bytes per row at 5-byte entries, 8.25 at u32) and a locate memo at every row (4 bytes) are
       // worth more than the last step of K: the table gets what they leave, and never more than a quarter of the free HBM
-      const double rest = fast_load ? 0.0 : (double)h.n * (h.n >= 0xfffffff0ull ? 14.25 : 12.25) + 8e9;
+      const double text_bytes = (double)h.n * (h.n >= 0xfffffff0ull ? 10.25 : 8.25);
+      const bool text_fits = text_bytes + (double)(h.n >> 3) <= 0.9 * (double)free_b;         // (the same test the text-mode block makes)
+      const double rest = fast_load ? 0.0 : (text_fits ? text_bytes : 0.0) + (double)h.n * 4.0 + 8e9;
       while (K > view_.ftab_width + 2 && ((16ull << (2 * K)) > free_b / 4 || (double)(16ull << (2 * K)) + rest > (double)free_b)) --K;
     }
     if (fast_load || balanced) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
@@ -386,7 +388,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     if (budget_gb < 0) {
       budget_gb = fast_load ? 0.0 : 16.0;
       size_t free_b = 0, total_b = 0;
-      if (!fast_load && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_gb = std::max(budget_gb, 0.6 * (double)free_b / 1e9);
+      // everything still free but 16 GB for the batch buffers: a memo at every row (4 bytes) is what makes the one-launch tail possible
+      if (!fast_load && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_gb = std::max(budget_gb, ((double)free_b - 16e9) / 1e9);
     }
     if (const char *e = dbg_env("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;

@@ -38,14 +38,49 @@ def test_native_writer_equals_reference_index_field_by_field(name, genomes, gold
     assert open(prefix + ".2.cfr", "rb").read() == open(os.path.join(golden_dir, name + ".2.cfr"), "rb").read()
 
 
+BUILD_MODES = {"default": {}, "many_chunks": {"CFR_BUILD_CHUNK_LOG2": "12"}, "host_sa_many_spans": {"CFR_BUILD_HOST_SA": "1", "CFR_BUILD_CHUNK_LOG2": "13"}}
+
+
+class _env:
+    def __init__(self, kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("mode", ["many_chunks", "host_sa_many_spans"])
+def test_writer_with_many_chunks_and_with_the_suffix_array_on_the_host(mode, genomes, golden_dir, tmp_path):
+    """The same 300 kbp text with 4096-row chunks (dozens of phase-1 chunks and phase-2 spans), and with the suffix array kept in
+    host memory (the form texts beyond ~24 Gbp take): the files must not change."""
+    g = genomes
+    prefix = str(tmp_path / mode)
+    with _env(BUILD_MODES[mode]):
+        capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=6)
+    mine, ref = parse_1cfr(prefix + ".1.cfr"), parse_1cfr(os.path.join(golden_dir, "f6.1.cfr"))
+    assert len(mine) == len(ref)
+    for (na, va), (nb, vb) in zip(mine, ref):
+        assert na == nb and va == vb, f"field {na} differs"
+
+
 def _naive_bwt(t):
     s = bytes(t.tolist())
     sa = sorted(range(len(s)), key=lambda i: s[i:])
     return sa
 
 
+@pytest.mark.parametrize("mode", sorted(BUILD_MODES))
 @pytest.mark.parametrize("kind", ["random", "long_repeat", "homopolymer_tail", "duplicate_genome", "periodic"])
-def test_suffix_order_on_adversarial_texts(kind, tmp_path):
+def test_suffix_order_on_adversarial_texts(kind, mode, tmp_path):
     """Texts that stress the doubling rounds and the end-of-text rule (a proper prefix sorts first): the written BWT /
     firstISA must be those of the naively sorted suffixes."""
     rng = np.random.default_rng(7)
@@ -64,7 +99,8 @@ def test_suffix_order_on_adversarial_texts(kind, tmp_path):
     seqs = [acgt[t[:n // 2]], acgt[t[n // 2:]]]
     g = synth.Genomes(["a", "b"], [1000, 1001], seqs, [(1, 1, "no rank"), (1000, 1, "species"), (1001, 1, "species")], [(1, "root"), (1000, "x"), (1001, "y")])
     prefix = str(tmp_path / kind)
-    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=4, rbbwt_b=1)
+    with _env(BUILD_MODES[mode]):
+        capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=4, rbbwt_b=1)
     sa = _naive_bwt(t)
     want_first_isa = sa.index(0)
     want_bwt = [int(t[p - 1]) if p else int(t[n - 1]) for p in sa]
