@@ -304,19 +304,20 @@ def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     paired = mode == "pe"
     k = 5 if paired else 1
     n = args.reads if paired else 200_000
-    idx = capi.Index(prefix, capi.default_params(max_result=k))
-    dev = capi.DeviceIndex(idx, device.index or 0)
     cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     starts = np.load(os.path.join(cache, "genome_starts.npy"))
-    cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
+    cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)       # (reads first, image second: see main)
     if paired:
         r1, r2 = make_pairs_gpu(torch, cat_d, starts, n, args.read_len, args.seed + 2000, device)
         offs_d = torch.arange(n + 1, device=device, dtype=torch.int64) * args.read_len
     else:
         r1, offs_d = make_long_reads_gpu(torch, cat_d, starts, n, args.seed + 3000, device)
         r2 = None
-    del cat_d
+    del cat_d, cat
+    torch.cuda.empty_cache()
     torch.cuda.synchronize()
+    idx = capi.Index(prefix, capi.default_params(max_result=k))
+    dev = capi.DeviceIndex(idx, device.index or 0)
     offs_h = offs_d.cpu().numpy().astype(np.uint64)
     total = int(offs_h[-1])
     res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
