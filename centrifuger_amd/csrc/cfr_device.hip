@@ -355,12 +355,12 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
         std::swap(ds_a, ds_b);
       }
       HIP_CHECK(hipGetLastError());
-      uint8_t *d_sa = dev_alloc<uint8_t>(h.n * esz + 64), *d_isa = dev_alloc<uint8_t>(h.n * esz + 64);   // + pad: slots are read 16 (32) bytes at a time
+      uint8_t *d_sa = dev_alloc<uint8_t>(h.n * esz + 256), *d_isa = dev_alloc<uint8_t>(h.n * esz + 256);   // + pad: a wide range reads 16 entries past its first row
       const uint64_t twords = (h.n + 31) / 32 + 4;
       uint64_t *d_text = dev_alloc<uint64_t>(twords) + 1;                                      // one pad word in front (see k_search_chains_v2)
       HIP_CHECK(hipMemsetAsync(d_text - 1, 0, twords * 8, stream_));
-      HIP_CHECK(hipMemsetAsync(d_sa + h.n * esz, 0, 64, stream_));
-      HIP_CHECK(hipMemsetAsync(d_isa + h.n * esz, 0, 64, stream_));
+      HIP_CHECK(hipMemsetAsync(d_sa + h.n * esz, 0, 256, stream_));
+      HIP_CHECK(hipMemsetAsync(d_isa + h.n * esz, 0, 256, stream_));
       if (wide) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
       else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
       HIP_CHECK(hipGetLastError());
@@ -605,6 +605,8 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
+    sv.wide_rows = kWideRows;
+    if (const char *e = dbg_env("CFR_WIDE_ROWS")) sv.wide_rows = std::min<uint32_t>(kWideRows, (uint32_t)atoi(e));
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
     if (dbg_env("CFR_SEARCH_PROF") && !paired && !wide) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
@@ -613,9 +615,9 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
       k_search_chains_v2<2, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt, d_prof);
       HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 16 * 8, hipMemcpyDeviceToHost, stream_));
       HIP_CHECK(hipStreamSynchronize(stream_));
-      static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "isa", "lane_iterations", "ext_two_records", "text_rows", "block_loads"};
+      static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "isa", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
-      for (int q = 0; q < 11; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
+      for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
     } else
     if (wide) {

@@ -29,6 +29,9 @@ VARIANTS = {
     # the n >= 2^32 code path (5-byte SA / ISA entries, WIDE search kernel) forced on the small indexes
     "wide_tables": {"CFR_FORCE_WIDE": "1"},
     "wide_tables_text_mode_early": {"CFR_FORCE_WIDE": "1", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
+    # ranges of 5 .. 24 rows continue on the text ("wide text mode"): off, and cut down to 6 rows
+    "no_wide_text_mode": {"CFR_WIDE_ROWS": "0"},
+    "wide_text_mode_6_rows_early": {"CFR_WIDE_ROWS": "6", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
@@ -42,4 +45,17 @@ def test_parity_suite_under_switches(name):
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, f"{name} {VARIANTS[name]}:\n{tail}"
+    assert " passed" in tail
+
+
+@pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"})])
+def test_many_strain_workload_under_switches(name, extra):
+    """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
+    tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""
+    env = dict(os.environ, CFR_DEBUG_ENV="1")
+    env.update(extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_scale.py"), "-m", "gpu", "-x", "-q", "-k", "strain"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0, f"{name}:\n{tail}"
     assert " passed" in tail
