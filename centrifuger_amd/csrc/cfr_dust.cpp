@@ -235,9 +235,11 @@ void scan_bounded(uint8_t *seg, size_t m) {
       int rvl = rv, max_score = 0, max_cnt = 1;
       uint64_t unfolded = rotr64(live, (unsigned)base), fresh = 0;
       const int first = size() - lv - 1;
+      int q_end = -1;       // a suffix's score never exceeds the window's (rw) and its triplet count only grows: stop where no start can qualify any more
       for (int q = first; q >= 0; --q) {
-        add(at(q), cv, rvl);
         const int triplets = size() - q - 1;
+        if (kThreshold * triplets >= rw * 10) { q_end = q; break; }
+        add(at(q), cv, rvl);
         if (rvl * 10 > kThreshold * triplets) {
           while (unfolded >> q) {
             const int p = 63 - __builtin_clzll(unfolded);
@@ -255,7 +257,7 @@ void scan_bounded(uint8_t *seg, size_t m) {
         }
       }
       live |= rotl64(fresh, (unsigned)base);
-      for (int q = first; q >= 0; --q) rem(at(q), cv, rvl);
+      for (int q = first; q > q_end; --q) rem(at(q), cv, rvl);
     }
   }
   size_t ws = wf + 1 > (size_t)kWindow ? wf + 1 - kWindow : 0;
