@@ -24,7 +24,7 @@ CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0 tools/pmc_passes.sh $O/${TAG}_pmc --no-pm
 python tools/pmc_summary.py $O/${TAG}_pmc > $O/${TAG}_pmc_summary.txt 2>> $O/${TAG}_pmc.log
 python tools/pmc_latest.py $O/${TAG}_pmc $TAG $O/${TAG}_pmc_latest.json >> $O/${TAG}_pmc.log 2>&1
 rm -rf $O/${TAG}_pmc/pmc*/
-CFR_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 3 --no-cpu-baseline > $O/${TAG}_bench_2ranks.json 2> $O/${TAG}_bench_2ranks.log
+CFR_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --steps 3 --no-cpu-baseline 2> $O/${TAG}_bench_2ranks.log | grep '^{"metric"' > $O/${TAG}_bench_2ranks.json   # (gloo prints its own lines on stdout)
 if [ -n "$BIG" ]; then
   python bench.py --index-gbp 8 --steps 3 --cpu-sample 500000 > $O/${TAG}_bench_8gbp.json 2> $O/${TAG}_bench_8gbp.log
 fi
