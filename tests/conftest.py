@@ -17,6 +17,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _torch_initialises_hip_first():
+    """Some GPU tests build their index with torch (tests/test_gpu_scale.py).  When libcfr_hip.so has made the process's first
+    HIP call and torch initialises afterwards, torch can report "No HIP GPUs are available" (seen with `pytest
+    tests/test_gpu_parity.py tests/test_gpu_scale.py`; the other order always works).  So torch goes first, once per session;
+    on a box without a GPU this does nothing."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_bin():
     """oracle/cfr_oracle (the plain-C restatement CLI); built on demand with gcc."""
