@@ -401,9 +401,55 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     if (budget_gb > 0 && fits32 && (1u << shift) < (uint32_t)h.sample_rate) try {
       const uint64_t entries = ((h.n - 1) >> shift) + 1;
       uint32_t *d_memo = dev_alloc<uint32_t>(entries);
-      k_build_loc_memo<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, shift, entries, d_memo);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      const unsigned gm = (unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 20);
+      bool filled = false;
+      const bool have_sa = wide_ ? view_.sa40 != nullptr : view_.sa32 != nullptr;
+      if (have_sa && !protein && !(dbg_env("CFR_MEMO_WALK") && atoi(dbg_env("CFR_MEMO_WALK")))) {
+        // from the text order (cfr_kernels.hip.inc, memo_step_value): breakpoints = position 0 and the selectedSA positions
+        const uint64_t nsel = h.selected_rows.size();
+        std::vector<uint64_t> bpos(nsel + 1, 0), bval(nsel + 1, 0);
+        if (nsel) {
+          uint64_t *d_p = (uint64_t *)temp_alloc(nsel * 8);
+          if (wide_) k_gather_sa<true><<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
+          else k_gather_sa<false><<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
+          HIP_CHECK(hipGetLastError());
+          HIP_CHECK(hipMemcpyAsync(bpos.data() + 1, d_p, nsel * 8, hipMemcpyDeviceToHost, stream_));
+          HIP_CHECK(hipStreamSynchronize(stream_));
+          temp_free(d_p);
+        }
+        std::vector<std::pair<uint64_t, uint64_t>> bp;
+        bp.emplace_back(0, h.adjusted_sa0);
+        for (uint64_t g = 0; g < nsel; ++g) if (h.selected_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], h.selected_vals[g]);
+        std::sort(bp.begin(), bp.end());
+        for (size_t g = 0; g < bp.size(); ++g) { bpos[g] = bp[g].first; bval[g] = bp[g].second; }
+        bpos.resize(bp.size()); bval.resize(bp.size());
+        uint64_t *d_bp = (uint64_t *)temp_alloc(bp.size() * 8), *d_bv = (uint64_t *)temp_alloc(bp.size() * 8);
+        unsigned long long *d_bad = (unsigned long long *)temp_alloc(8), bad = 0;
+        HIP_CHECK(hipMemcpyAsync(d_bp, bpos.data(), bp.size() * 8, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipMemcpyAsync(d_bv, bval.data(), bp.size() * 8, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, stream_));
+        const MemoSteps S{d_bp, d_bv, (uint64_t)bp.size()};
+        const uint64_t nsamp = (h.n + h.sample_rate - 1) / h.sample_rate;
+        const unsigned gs = (unsigned)std::min<uint64_t>((nsamp + 255) / 256, 1u << 20);
+        if (wide_) k_memo_check<true><<<gs, 256, 0, stream_>>>(view_, S, nsamp, d_bad);
+        else k_memo_check<false><<<gs, 256, 0, stream_>>>(view_, S, nsamp, d_bad);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        if (bad == 0) {
+          if (wide_) k_memo_fill<true><<<gm, 256, 0, stream_>>>(view_, S, shift, entries, d_memo);
+          else k_memo_fill<false><<<gm, 256, 0, stream_>>>(view_, S, shift, entries, d_memo);
+          HIP_CHECK(hipGetLastError());
+          HIP_CHECK(hipStreamSynchronize(stream_));
+          filled = true;
+        }
+        temp_free(d_bp); temp_free(d_bv); temp_free(d_bad);
+      }
+      if (!filled) {
+        k_build_loc_memo<<<gm, 256, 0, stream_>>>(view_, shift, entries, d_memo);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream_));
+      }
       view_.loc_memo = d_memo;
       view_.memo_shift = shift;
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table

@@ -32,6 +32,8 @@ VARIANTS = {
     # ranges of 5 .. 24 rows continue on the text ("wide text mode"): off, and cut down to 6 rows
     "no_wide_text_mode": {"CFR_WIDE_ROWS": "0"},
     "wide_text_mode_6_rows_early": {"CFR_WIDE_ROWS": "6", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
+    # the locate memo built by the plain LF walk per row instead of from the text order
+    "memo_by_walk": {"CFR_MEMO_WALK": "1"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
