@@ -802,9 +802,25 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
 void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, hipStream_t st) {
   if (n == 0) return;
   const unsigned blocks = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
-  uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2, (size_t)blocks * kDustBlock * 64 * sizeof(uint32_t));   // one table per stream
+  uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2,
+                                       ((size_t)blocks * kDustBlock * 64 + kDustPoolHead) * sizeof(uint32_t));   // one table per stream
+  HIP_CHECK(hipMemsetAsync(pool, 0, kDustPoolHead * sizeof(uint32_t), st));      // the counter the lanes draw reads from
   k_dust<<<blocks, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool);
   HIP_CHECK(hipGetLastError());
+#ifdef CFR_DUST_PROF
+  {
+    unsigned long long h[16];
+    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(dust_prof), sizeof(h)));
+    static const char *nm[5] = {"step", "slow", "trim", "find", "next"};
+    const double waves = (double)blocks * kDustBlock / 64;
+    for (int k = 0; k < 5; ++k)
+      fprintf(stderr, "[dust] %s rounds %llu lanes %llu (%.1f per round)  clocks per wave %.0f (%.0f per round)\n", nm[k], h[2 * k], h[2 * k + 1],
+              h[2 * k] ? (double)h[2 * k + 1] / h[2 * k] : 0.0, h[10 + k] / waves, h[2 * k] ? (double)h[10 + k] / h[2 * k] : 0.0);
+    unsigned long long z[16] = {0};
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(dust_prof), z, sizeof(z)));
+  }
+#endif
 }
 
 void DeviceIndex::dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n) {
