@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_HEAVY, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -95,6 +95,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
   if (const char *e = dbg_env("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
+  if (const char *e = dbg_env("CFR_TEAM_TAIL")) team_tail_ = atoi(e) != 0;
   if (const char *e = dbg_env("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
   else if (const char *e2 = dbg_env("CFR_POOL_INIT")) pool_cap_ = strtoull(e2, nullptr, 10);  // first size (grows on overflow)
   if (opt.sub_batch) sub_batch_ = (size_t)opt.sub_batch;
@@ -1025,15 +1026,24 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         if (attempt == 0) { bring_piece(k); pack_piece(k); }
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
-        unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 16);    // pool cursor, overflow flag
+        unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 32);    // pool cursor, overflow flag, heavy reads
         cfr_result *d_res;
         cfr_match *d_match;
         out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
-        HIP_CHECK(hipMemsetAsync(ctl, 0, 16, stream_));
+        HIP_CHECK(hipMemsetAsync(ctl, 0, 32, stream_));
+        // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
+        uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(S_HEAVY, std::max(sb, cnt) * 16) : nullptr;
         if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                           pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+                                                                           pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
         else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                    pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+                                                                    pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
+        if (heavy) {
+          const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * 5));
+          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, stream_>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+                                                                                (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, stream_>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+                                                                         (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+        }
         HIP_CHECK(hipGetLastError());
         copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);

@@ -184,7 +184,7 @@ def test_many_near_identical_strains_general_fold(tmp_path):
     two-kernel path on every read, against the plain FM-index walk, and against the C oracle on a subsample."""
     import torch
     from centrifuger_amd import indexbuild
-    k = 2
+    k = int(os.environ.get("CFR_TEST_K", "2"))     # (tests/test_gpu_variants.py runs this with -k 1 and -k 5 too: LCA by the team, listings)
     g = synth.make_genomes(8, 20, 60_000, seed=991, divergence_step=0.001)
     prefix = str(tmp_path / "idx")
     indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))

@@ -34,6 +34,8 @@ VARIANTS = {
     "wide_text_mode_6_rows_early": {"CFR_WIDE_ROWS": "6", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     # the locate memo built by the plain LF walk per row instead of from the text order
     "memo_by_walk": {"CFR_MEMO_WALK": "1"},
+    # reads with many located rows folded by one lane through the pool (tail_fold_hash) instead of a team (k_tail_heavy)
+    "no_team_tail": {"CFR_TEAM_TAIL": "0"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
@@ -50,7 +52,8 @@ def test_parity_suite_under_switches(name):
     assert " passed" in tail
 
 
-@pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"})])
+@pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"}),
+                                        ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"})])
 def test_many_strain_workload_under_switches(name, extra):
     """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
     tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""
