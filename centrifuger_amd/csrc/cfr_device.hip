@@ -1032,7 +1032,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
         HIP_CHECK(hipMemsetAsync(ctl, 0, 32, stream_));
         // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
-        uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(S_HEAVY, std::max(sb, cnt) * 16) : nullptr;
+        uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
         if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                            pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
         else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
