@@ -997,8 +997,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipEventRecord(ev_[7], stream_));
     HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
     HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
-    HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
-    if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+    static const bool no_copy = dbg_env("CFR_NO_COPY_OUT") && atoi(dbg_env("CFR_NO_COPY_OUT"));     // diagnosis: the step without its D2H
+    if (!no_copy) {
+      HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
+      if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+    }
     if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   };

@@ -71,6 +71,50 @@ def test_device_masks_equal_host_masks(dev):
     assert int((host != b).sum()) > 100_000          # the mix really has low-complexity sequence
 
 
+def test_non_symbol_runs_at_every_place(dev):
+    """Where the device scan takes its side paths: non-symbols at the first, second and third base, leading / trailing /
+    inner runs around the 64-base limit (a longer run closes the segment, the next one starts from scratch), several runs
+    in one read with low-complexity stretches between them, reads of non-symbols only - at every alignment of the buffer."""
+    idx, d = dev
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = []
+
+    def lowc(L):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            return np.full(L, acgt[rng.integers(0, 4)], dtype=np.uint8)
+        if kind == 1:
+            return np.resize(acgt[rng.integers(0, 4, size=int(rng.integers(2, 5)))], L)
+        return acgt[rng.integers(0, 4, size=L)]
+
+    for lead in (0, 1, 2, 3, 5, 63, 64, 65, 66, 130):
+        for inner in (0, 1, 2, 63, 64, 65, 66, 100):
+            for trail in (0, 1, 2, 64, 65, 70):
+                parts = [np.full(lead, ord("N"), dtype=np.uint8), lowc(int(rng.integers(1, 120)))]
+                if inner:
+                    parts += [np.full(inner, ord("n" if inner % 2 else "N"), dtype=np.uint8), lowc(int(rng.integers(1, 120)))]
+                    if inner in (2, 65):
+                        parts += [np.full(inner + 1, ord("X"), dtype=np.uint8), lowc(int(rng.integers(3, 90)))]
+                parts.append(np.full(trail, ord("N"), dtype=np.uint8))
+                out.append(np.concatenate(parts))
+    for L in (0, 1, 2, 3, 4, 63, 64, 65, 200):
+        out.append(np.full(L, ord("N"), dtype=np.uint8))
+        out.append(np.concatenate([np.array([ord("A")], dtype=np.uint8), np.full(L, ord("N"), dtype=np.uint8), lowc(40)]))
+        out.append(np.concatenate([np.array([ord("A"), ord("C")], dtype=np.uint8), np.full(L, ord("N"), dtype=np.uint8), lowc(40)]))
+    b = np.concatenate(out)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in out])]).astype(np.uint64)
+    host = b.copy()
+    capi.dust_mask(host, o, threads=1, literal=True)
+    for shift in (0, 1, 2, 3, 5):                      # the buffer's alignment moves the 4-byte refills of the base window
+        buf = np.concatenate([np.full(shift, ord("G"), dtype=np.uint8), b])
+        oo = np.concatenate([[0], o + np.uint64(shift)]).astype(np.uint64)
+        got = buf.copy()
+        d.dust_mask(got, oo)
+        assert np.array_equal(got[shift:], host), shift
+        assert np.array_equal(got[:shift], buf[:shift])
+
+
 def test_long_homopolymers_and_repeats(dev):
     """A 6 kbp homopolymer drives the reference's list of perfect intervals to its maximum (1711 entries, rescanned per window
     suffix); the device keeps one entry per start instead and must still produce the same masks."""

@@ -210,6 +210,47 @@ def test_many_near_identical_strains_general_fold(tmp_path):
     assert float((res["n_match"] > 0).mean()) > 0.99
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_families_of_70_strains_team_fold_limits(tmp_path, k):
+    """70 near-identical strains per species: ranges of up to 70 rows.  With -k 1 a hit locates 40 of them by the strided
+    enumeration of Classifier.hpp:640-666 (the team kernel's two-pass row sequence); with -k 3 all 70 (more entries than the
+    team's table takes: the single-lane form from inside k_tail_heavy, also with the pool too small at first).  Single-end and
+    pairs, against the sort-based fold of the two-kernel path on every read and against the C oracle on a subsample."""
+    import torch
+    from centrifuger_amd import indexbuild
+    g = synth.make_genomes(3, 70, 30_000, seed=1203, divergence_step=0.0003)
+    prefix = str(tmp_path / "idx")
+    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    n = 60_000
+    rs = synth.make_reads(g, n, 150, seed=1204, sub_rate=0.004, n_rate=0.0005)
+    r1, r2 = synth.make_pairs(g, 20_000, 125, seed=1205)
+    idx, dev = _open(prefix, k, {"CFR_POOL_INIT": "1000"})
+    res, mat = dev.classify(rs.bases, rs.offsets)
+    ref = digest(*canon(res, mat, k))
+    res_b, mat_b = dev.classify(rs.bases, rs.offsets)            # the pool has grown by now: same answers
+    assert digest(*canon(res_b, mat_b, k)) == ref
+    resp, matp = dev.classify(r1.bases, r1.offsets, r2.bases, r2.offsets)
+    refp = digest(*canon(resp, matp, k))
+    dev.close()
+    for env in ({"CFR_FUSED_POST": "0"}, {"CFR_TEAM_TAIL": "0"}):
+        idx2, dev2 = _open(prefix, k, env)
+        r2_, m2_ = dev2.classify(rs.bases, rs.offsets)
+        assert digest(*canon(r2_, m2_, k)) == ref, env
+        r3_, m3_ = dev2.classify(r1.bases, r1.offsets, r2.bases, r2.offsets)
+        assert digest(*canon(r3_, m3_, k)) == refp, env
+        dev2.close()
+    o = ora.OracleIndex(prefix, max_result=k)
+    m = 1500
+    ores = o.classify(rs.bases[:m * 150], rs.offsets[:m + 1], threads=16)
+    for i in range(m):
+        assert idx.format_tsv("r", res[i], mat) == o.format("r", ores[i]), i
+    mp = 500
+    oresp = o.classify(r1.bases[:int(r1.offsets[mp])], r1.offsets[:mp + 1], r2.bases[:int(r2.offsets[mp])], r2.offsets[:mp + 1], threads=16)
+    for i in range(mp):
+        assert idx.format_tsv("r", resp[i], matp) == o.format("r", oresp[i]), i
+    o.close()
+
+
 def test_ragged_reads_fuzz_against_oracle(world, tmp_path):
     """Reads of every length from 1 to 300 at every alignment of the flat buffer (the 16-byte packed blocks and the
     64-character register queue of the search kernel see every phase), with substitutions, N, lower case, pure noise, mates
