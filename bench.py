@@ -299,6 +299,62 @@ def live_pmc(args, cache):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def cache_key(args):
+    return hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")
+                        + ("-fastgen" if args.index_gbp else "")).encode()).hexdigest()[:10]
+
+
+def strains_config(torch, capi, ora, args, device):
+    """The data-sensitivity case as a sub-result: 25 species x 20 strains 0.1 % apart x 2 Mbp (1 Gbp), the metric's reads
+    (10 M x 150 bp SE, -k 1): ranges of ~20 rows per hit (wide text mode in the search, k_tail_heavy in the tail)."""
+    a2 = argparse.Namespace(**vars(args))
+    a2.species, a2.strains, a2.genome_len, a2.divergence_step, a2.index_gbp = 25, 20, 2_000_000, 0.001, 0.0
+    cache = os.path.join(args.cache, cache_key(a2))
+    prefix = build_index(a2, cache, device)
+    torch.cuda.empty_cache()
+    cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
+    starts = np.load(os.path.join(cache, "genome_starts.npy"))
+    cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
+    n = args.reads
+    reads_d = make_reads_gpu(torch, cat_d, starts, n, args.read_len, args.seed + 4000, device)
+    offs_d = torch.arange(n + 1, device=device, dtype=torch.int64) * args.read_len
+    del cat_d, cat
+    torch.cuda.empty_cache()
+    idx = capi.Index(prefix, capi.default_params(max_result=1))
+    dev = capi.DeviceIndex(idx, device.index or 0)
+    total = n * args.read_len
+    res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
+    mat_pin = capi.PinnedArray(n, capi.MATCH_DTYPE)
+
+    def step():
+        return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
+    step()
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    st = dev.last_stats()
+    nchk = 5000
+    b1 = reads_d.reshape(-1)[:nchk * args.read_len].cpu().numpy()
+    offs_h = (np.arange(nchk + 1, dtype=np.uint64) * np.uint64(args.read_len))
+    oo = ora.OracleIndex(prefix, max_result=1)
+    ores = oo.classify(b1, offs_h, dust=False, threads=min(os.cpu_count() or 1, 64))
+    res, mat = res_pin.array, mat_pin.array
+    same = all(idx.format_tsv("r", res[i], mat) == oo.format("r", ores[i]) for i in range(nchk))
+    out = {"value": n * steps / el, "unit": "reads/s", "ms_per_step": 1000 * el / steps, "steps": steps,
+           "workload": f"{idx.info().n/1e9:.2f} Gbp index of 25 species x 20 strains 0.1 % apart, {n} x {args.read_len} bp SE reads, -k 1, inputs resident in HBM",
+           "search_ms": st.search_ms, "tail_ms": st.tail_ms, "classified_fraction": float((res["n_match"] > 0).mean()),
+           "tsv_lines_equal_oracle_on_first": nchk, "equals_oracle": bool(same)}
+    oo.close()
+    res_pin.free()
+    mat_pin.free()
+    dev.close()
+    return out
+
+
 def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     """One of the other BASELINE configs on the same index: timed steps with resident inputs + a check against the C oracle."""
     paired = mode == "pe"
@@ -384,7 +440,12 @@ def main():
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
                          "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")
     ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
+    ap.add_argument("--workload", choices=["cfg2", "strains20"], default="cfg2",
+                    help="cfg2 = the metric's index (50 species x 5 strains 1 %% apart); strains20 = the data-sensitivity case: "
+                         "25 species x 20 strains 0.1 %% apart x 2 Mbp (ranges of ~20 rows per hit: wide text mode, team fold)")
     args = ap.parse_args()
+    if args.workload == "strains20":
+        args.species, args.strains, args.genome_len, args.divergence_step = 25, 20, 2_000_000, 0.001
     if args.index_gbp:
         args.species = max(1, int(round(args.index_gbp * 1e9 / (args.strains * args.genome_len))))
 
@@ -424,8 +485,7 @@ def main():
     all_cpus = os.sched_getaffinity(0)
     numa = bind_to_gpu_numa_node(torch, local_rank)      # host threads + pinned buffers next to this rank's GPU
     from centrifuger_amd import capi
-    key = hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")
-                       + ("-fastgen" if args.index_gbp else "")).encode()).hexdigest()[:10]
+    key = cache_key(args)
     cache = os.path.join(args.cache, key)
     if rank == 0:
         prefix = build_index(args, cache, device)
@@ -755,6 +815,11 @@ def main():
                 out["other_configs"][m] = extra_config(torch, capi, ora, args, m, prefix, cache, device)
             except Exception as e:
                 out["other_configs"][m] = {"error": repr(e)}
+        if args.workload == "cfg2" and not args.index_gbp:
+            try:
+                out["other_configs"]["strains20"] = strains_config(torch, capi, ora, args, device)
+            except Exception as e:
+                out["other_configs"]["strains20"] = {"error": repr(e)}
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
