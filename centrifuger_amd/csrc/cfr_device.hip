@@ -357,9 +357,9 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       }
       HIP_CHECK(hipGetLastError());
       uint8_t *d_sa = dev_alloc<uint8_t>(h.n * esz + 256), *d_isa = dev_alloc<uint8_t>(h.n * esz + 256);   // + pad: a wide range reads 16 entries past its first row
-      const uint64_t twords = (h.n + 31) / 32 + 4;
-      uint64_t *d_text = dev_alloc<uint64_t>(twords) + 1;                                      // one pad word in front (see k_search_chains_v2)
-      HIP_CHECK(hipMemsetAsync(d_text - 1, 0, twords * 8, stream_));
+      const uint64_t twords = (h.n + 31) / 32 + 6;
+      uint64_t *d_text = dev_alloc<uint64_t>(twords) + 2;                                      // 16 bytes of padding in front (see k_search_chains_v2: text_slot)
+      HIP_CHECK(hipMemsetAsync(d_text - 2, 0, twords * 8, stream_));
       HIP_CHECK(hipMemsetAsync(d_sa + h.n * esz, 0, 256, stream_));
       HIP_CHECK(hipMemsetAsync(d_isa + h.n * esz, 0, 256, stream_));
       if (wide) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
