@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_HEAVY, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -802,11 +802,26 @@ void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, c
 // place, asynchronously on `st` (k_dust; bounded per-lane state, no host involvement).
 void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, hipStream_t st) {
   if (n == 0) return;
-  const unsigned blocks = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
+  // reads of A, C, G, T only go through the instantiation with 64-triplet tables (three waves per SIMD), the others
+  // (flagged by one pass over the bases) through the one with 125; CFR_DUST_SPLIT=0: everything through the latter
+  static const bool split = !(dbg_env("CFR_DUST_SPLIT") && atoi(dbg_env("CFR_DUST_SPLIT")) == 0);
+  const unsigned blocks_pure = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 6));
+  const unsigned blocks_any = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
   uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2,
-                                       ((size_t)blocks * kDustBlock * 64 + kDustPoolHead) * sizeof(uint32_t));   // one table per stream
-  HIP_CHECK(hipMemsetAsync(pool, 0, kDustPoolHead * sizeof(uint32_t), st));      // the counter the lanes draw reads from
-  k_dust<<<blocks, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool);
+                                       ((size_t)(blocks_pure + blocks_any) * kDustBlock * 64 + kDustPoolHead) * sizeof(uint32_t));   // one table per stream
+  HIP_CHECK(hipMemsetAsync(pool, 0, kDustPoolHead * sizeof(uint32_t), st));      // the counters the lanes draw reads from
+  if (split) {
+    // flags: a byte per read; behind them (8-byte aligned) the list of flagged reads; its length is the third counter of the pool head
+    const size_t flag_bytes = (n + 16 + 7) & ~(size_t)7;
+    uint8_t *flags = (uint8_t *)scratch(st == stream_ ? S_DUSTFLAG : S_DUSTFLAG2, flag_bytes + n * 4);
+    uint32_t *list = (uint32_t *)(flags + flag_bytes);
+    unsigned long long *list_cnt = (unsigned long long *)pool + 2;
+    k_dust_flags<<<std::min<unsigned>((unsigned)((n + 255) / 256), (unsigned)(num_cus_ * 16)), 256, 0, st>>>(d_bases, d_offs, n, flags, list, list_cnt);
+    // one after the other: side by side (second stream) the 125-triplet blocks take the LDS first and both get slower
+    // (measured: 10.5 ms against 10.85 with 14 % flagged reads, 12.5 ms with its grid cut to the flagged count)
+    k_dust<true><<<blocks_pure, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool, 0, flags, nullptr, nullptr);
+    k_dust<false><<<blocks_any, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool, blocks_pure, flags, list, list_cnt);
+  } else k_dust<false><<<blocks_any, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool, 0, nullptr, nullptr, nullptr);
   HIP_CHECK(hipGetLastError());
 #ifdef CFR_DUST_PROF
   {

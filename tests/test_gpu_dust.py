@@ -182,3 +182,16 @@ def test_device_masks_equal_the_reference_dumps(dev):
     bad = [ids[i] for i in range(len(ids)) if bytes(got[int(o[i]):int(o[i + 1])]) != want[ids[i]]]
     assert not bad, bad[:10]
     assert sum(1 for i in range(len(ids)) if bytes(b[int(o[i]):int(o[i + 1])]) != want[ids[i]]) > 500
+
+
+def test_one_instantiation_for_all_reads():
+    """The same tests with CFR_DUST_SPLIT=0: every read through the 125-triplet instantiation of k_dust (no flag pass, no
+    ACGT-only instantiation) - the two forms must mask alike."""
+    import subprocess
+    import sys
+    env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_DUST_SPLIT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-k", "not one_instantiation"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in tail

@@ -11,5 +11,11 @@ for f in glob.glob("/tmp/dustp_$lc/**/*kernel_stats.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "dust" in r["Name"]:
             print("lowc $lc:", r["Name"][:48], "calls", r["Calls"], "avg ms %.2f" % (float(r["AverageNs"]) / 1e6))
+for f in glob.glob("/tmp/dustp_$lc/**/*kernel_trace.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "dust" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    calls = [rows[i:i + 3] for i in range(0, len(rows), 3)] if len(rows) % 3 == 0 else []
+    for c in calls[-1:]:
+        print("lowc $lc: span of the last call's dust kernels %.2f ms" % ((max(int(r["End_Timestamp"]) for r in c) - min(int(r["Start_Timestamp"]) for r in c)) / 1e6))
 PY
 done
