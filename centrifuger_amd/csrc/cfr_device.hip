@@ -829,7 +829,7 @@ void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_
     HIP_CHECK(hipStreamSynchronize(st));
     HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(dust_prof), sizeof(h)));
     static const char *nm[5] = {"step", "slow", "trim", "find", "next"};
-    const double waves = (double)blocks * kDustBlock / 64;
+    const double waves = (double)(blocks_pure + blocks_any) * kDustBlock / 64;      // (both launches add into the same counters)
     for (int k = 0; k < 5; ++k)
       fprintf(stderr, "[dust] %s rounds %llu lanes %llu (%.1f per round)  clocks per wave %.0f (%.0f per round)\n", nm[k], h[2 * k], h[2 * k + 1],
               h[2 * k] ? (double)h[2 * k + 1] / h[2 * k] : 0.0, h[10 + k] / waves, h[2 * k] ? (double)h[10 + k] / h[2 * k] : 0.0);
