@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -94,6 +94,10 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking));
+  for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  if (const char *e = dbg_env("CFR_TAIL_STREAM")) tail_overlap_mode_ = atoi(e) != 0 ? 1 : 0;
+  if (const char *e = dbg_env("CFR_TAIL_BLOCKS")) tail_blocks_per_cu_ = atoi(e);
   if (const char *e = dbg_env("CFR_FUSED_POST")) fused_post_ = atoi(e) != 0;
   if (const char *e = dbg_env("CFR_TEAM_TAIL")) team_tail_ = atoi(e) != 0;
   if (const char *e = dbg_env("CFR_POOL_CAP")) pool_cap_ = strtoull(e, nullptr, 10);        // fixed size (no growth)
@@ -478,7 +482,9 @@ void DeviceIndex::release() {            // idempotent: also the clean-up of a c
   for (auto &e : tail_done_) drop_event(e);
   for (auto &e : copy_done_) drop_event(e);
   for (auto &e : h2d_done_) drop_event(e);
+  for (auto &e : search_done_) drop_event(e);
   auto drop_stream = [](hipStream_t &s) { if (s) (void)hipStreamDestroy(s); s = nullptr; };
+  drop_stream(tail_stream_);
   drop_stream(h2d_stream_);
   drop_stream(copy_stream_);
   drop_stream(stream_);
@@ -605,7 +611,7 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 // size the dense arrays; everything else stays on the device.  Two halves: launch_search (caps, scan, the search kernel)
 // is also what the one-launch post stage of classify_device follows; launch_post is everything behind the search kernel.
 DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                                  uint64_t total1, uint64_t total2) {
+                                                  uint64_t total1, uint64_t total2, int par) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -614,12 +620,13 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
 
   if (view_.prot.enabled) return launch_search_protein(d_b1, d_o1, d_b2, d_o2, n, total1, total2);
-  uint64_t *cap = (uint64_t *)scratch(S_CAP, (n + 1) * 8);
-  uint64_t *hit_off = (uint64_t *)scratch(S_HITOFF, (n + 1) * 8);
-  cfr_hit *raw = (cfr_hit *)scratch(S_RAW, cap_total * sizeof(cfr_hit));
-  uint32_t *chain_cnt = (uint32_t *)scratch(S_CHAINCNT, nchains * 4);
+  // two sets of output buffers: the post stage of sub-batch k (its own stream) reads one while the search of k + 1 fills the other
+  uint64_t *cap = (uint64_t *)scratch(par ? S_CAP1 : S_CAP, (n + 1) * 8);
+  uint64_t *hit_off = (uint64_t *)scratch(par ? S_HITOFF1 : S_HITOFF, (n + 1) * 8);
+  cfr_hit *raw = (cfr_hit *)scratch(par ? S_RAW1 : S_RAW, cap_total * sizeof(cfr_hit));
+  uint32_t *chain_cnt = (uint32_t *)scratch(par ? S_CHAINCNT1 : S_CHAINCNT, nchains * 4);
   size_t tmp_bytes = scan_tmp_bytes(n);
-  void *tmp = scratch(S_SCAN, tmp_bytes);
+  void *tmp = scratch(par ? S_SCAN1 : S_SCAN, tmp_bytes);
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
   HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
@@ -1002,15 +1009,20 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     if (paired) one(src->o2, d_b2, total2, packed2_);
     HIP_CHECK(hipGetLastError());
   };
+  // the post stage beside the next sub-batch's search: pays when the post stage is long (reads over families of strains:
+  // 20-strain workload 2.97e8 -> 3.3e8 reads/s) and costs when it is short (cfg2: the search runs 20 % slower with anything
+  // beside it, 6.8e8 -> 6.3e8).  The share of reads the last call folded by teams decides (CFR_TAIL_STREAM=0/1 forces it).
+  const bool tail_overlap = tail_overlap_mode_ >= 0 ? tail_overlap_mode_ != 0 : heavy_frac_ > 0.2;
   if (src && !one_launch) throw HipError{"streamed host inputs need the one-launch post stage", -4};
   bring_piece(0);
 
   // results / matches of piece k leave through the buffer pair of its parity while piece k+1 computes
-  auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag) {
+  auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag, hipStream_t st,
+                      const void *d_heavy = nullptr, unsigned long long *h_heavy = nullptr) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
-    HIP_CHECK(hipEventRecord(ev_[7], stream_));
-    HIP_CHECK(hipEventRecord(tail_done_[par], stream_));
+    HIP_CHECK(hipEventRecord(ev_[7], st));
+    HIP_CHECK(hipEventRecord(tail_done_[par], st));
     HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
     static const bool no_copy = dbg_env("CFR_NO_COPY_OUT") && atoi(dbg_env("CFR_NO_COPY_OUT"));     // diagnosis: the step without its D2H
     if (!no_copy) {
@@ -1018,20 +1030,23 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
     }
     if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
+    if (d_heavy) HIP_CHECK(hipMemcpyAsync(h_heavy, d_heavy, 8, hipMemcpyDeviceToHost, copy_stream_));
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   };
-  auto out_buffers = [&](size_t k, uint64_t extent, cfr_result *&d_res, cfr_match *&d_match) {
+  auto out_buffers = [&](size_t k, uint64_t extent, cfr_result *&d_res, cfr_match *&d_match, hipStream_t st) {
     const int par = (int)(k & 1);
     d_res = (cfr_result *)scratch(par ? S_RESULTS1 : S_RESULTS, std::max(pieces[k].second, sb) * sizeof(cfr_result));
     d_match = (cfr_match *)scratch(par ? S_MATCHES1 : S_MATCHES, (std::max<uint64_t>(extent, stride * sb) + 1) * sizeof(cfr_match));
-    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(stream_, copy_done_[par], 0));      // the copy that read this buffer pair
+    if (k >= 2) HIP_CHECK(hipStreamWaitEvent(st, copy_done_[par], 0));           // the copy that read this buffer pair
   };
 
   // ---- one launch per piece behind the search: everything is enqueued at once
   std::vector<size_t> todo;                 // pieces still to do
   for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
-    uint32_t *ovf = (uint32_t *)pinned((2 + kMaxSub) * 8) + 4;      // behind the two u64 totals
+    uint32_t *ovf = (uint32_t *)pinned((2 + 2 * kMaxSub) * 8) + 4;  // behind the two u64 totals
+    unsigned long long *heavy_h = (unsigned long long *)pinned((2 + 2 * kMaxSub) * 8) + 2 + kMaxSub;   // reads k_tail_heavy folded, per sub-batch
+    for (size_t k = 0; k < kMaxSub; ++k) heavy_h[k] = 0;
     if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
     const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
     for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
@@ -1042,34 +1057,52 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         ovf[k] = 0;
         ev_ = evs_[k];
         if (attempt == 0) { bring_piece(k); pack_piece(k); }
-        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2);
+        // the post stage runs on its own stream: it is a chain of dependent gathers per read (4 fabric requests per read,
+        // waves waiting two thirds of the time) and hides under the search of the next sub-batch, which is bound by the
+        // fabric's request rate.  Two sets of search outputs: search k + 2 waits for the post stage of k.
+        const int par = tail_overlap ? (int)(k & 1) : 0;
+        hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
+        if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
+        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, par);
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
+        if (tail_overlap) {
+          HIP_CHECK(hipEventRecord(search_done_[par], stream_));
+          HIP_CHECK(hipStreamWaitEvent(ts, search_done_[par], 0));
+        }
         unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 32);    // pool cursor, overflow flag, heavy reads
         cfr_result *d_res;
         cfr_match *d_match;
-        out_buffers(k, stride * cnt, d_res, d_match);                   // (also orders the memset below behind the copy of ctl)
-        HIP_CHECK(hipMemsetAsync(ctl, 0, 32, stream_));
+        out_buffers(k, stride * cnt, d_res, d_match, ts);               // (also orders the memset below behind the copy of ctl)
+        HIP_CHECK(hipMemsetAsync(ctl, 0, 32, ts));
         // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
-        uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
-        if (paired) k_adjust_tail<4><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                           pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
-        else k_adjust_tail<2><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                    pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
+        uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
+        // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
+        const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
+        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
+        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
         if (heavy) {
-          const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * 5));
-          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, stream_>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
-                                                                                (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, stream_>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
-                                                                         (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+          const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * (tail_overlap && tail_blocks_per_cu_ ? std::min(5, 2 * tail_blocks_per_cu_) : 5)));
+          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+                                                                           (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+                                                                    (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
         }
         HIP_CHECK(hipGetLastError());
-        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k]);
+        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k], ts, heavy ? ctl + 2 : nullptr, &heavy_h[k]);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
       HIP_CHECK(hipStreamSynchronize(stream_));
+      HIP_CHECK(hipStreamSynchronize(tail_stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
       if (attempt == 0) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+      if (attempt == 0) {                    // what the next call's schedule goes by: the share of reads with a team fold
+        unsigned long long hv = 0;
+        for (size_t k = 0; k < nsub; ++k) hv += heavy_h[k];
+        heavy_frac_ = (double)hv / (double)n;
+      }
       std::vector<size_t> again;
       for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
       todo.swap(again);
@@ -1093,13 +1126,13 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     TailEntry *entries = (TailEntry *)scratch(S_ENTRIES, (p.nrows + 1) * sizeof(TailEntry));
     cfr_result *d_res;
     cfr_match *d_match;
-    out_buffers(k, extent, d_res, d_match);
+    out_buffers(k, extent, d_res, d_match, stream_);
     if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
                                                                   p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
                                                               p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
-    copy_out(k, d_res, d_match, extent, nullptr, nullptr);
+    copy_out(k, d_res, d_match, extent, nullptr, nullptr, stream_);
   }
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));

@@ -172,7 +172,7 @@ class DeviceIndex {
                          bool fused = false);
   struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
   SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                          uint64_t total1, uint64_t total2);
+                          uint64_t total1, uint64_t total2, int par = 0);
   SearchBuf launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
@@ -196,7 +196,11 @@ class DeviceIndex {
   static constexpr size_t kMaxSub = 16;
   hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 around the search, 8 and 3-7 around the stages behind it
   hipEvent_t *ev_ = nullptr;
-  hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr;
+  hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr, tail_stream_ = nullptr;
+  hipEvent_t search_done_[2] = {};
+  int tail_overlap_mode_ = -1;           // the post stage of a sub-batch beside the search of the next one: -1 = by heavy_frac_, 0 / 1
+  double heavy_frac_ = 0.0;              // share of the last call's reads that k_tail_heavy folded
+  int tail_blocks_per_cu_ = 0;           // blocks per CU of the post stage when it runs beside a search (0: one lane per read)
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {};
   size_t sub_batch_ = 1250000, taper_floor_ = 262144;
   int num_cus_ = 256, blocks_per_cu_ = 7;

@@ -36,6 +36,10 @@ VARIANTS = {
     "memo_by_walk": {"CFR_MEMO_WALK": "1"},
     # reads with many located rows folded by one lane through the pool (tail_fold_hash) instead of a team (k_tail_heavy)
     "no_team_tail": {"CFR_TEAM_TAIL": "0"},
+    # the post stage on the search's own stream (no overlap with the next sub-batch's search), with several sub-batches
+    "post_stage_on_the_search_stream": {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "97", "CFR_TAPER_FLOOR": "0"},
+    "post_stage_overlapped_many_subbatches": {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0"},
+    "post_stage_overlapped_grid_stride": {"CFR_TAIL_STREAM": "1", "CFR_TAIL_BLOCKS": "1", "CFR_SUBBATCH": "1000", "CFR_TAPER_FLOOR": "0"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
 }
 
@@ -53,7 +57,9 @@ def test_parity_suite_under_switches(name):
 
 
 @pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"}),
-                                        ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"})])
+                                        ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"}),
+                                        ("post_stage_overlapped", {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "20000"}),
+                                        ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"})])
 def test_many_strain_workload_under_switches(name, extra):
     """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
     tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""
