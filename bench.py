@@ -328,7 +328,8 @@ def strains_config(torch, capi, ora, args, device):
 
     def step():
         return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
-    step()
+    step()          # (the scratch pool of the single-lane folds grows on the way, and the library picks its schedule - post stage
+    step()          #  beside the next search or behind it - from what the previous call saw: two untimed steps)
     torch.cuda.synchronize()
     steps = 3
     t0 = time.perf_counter()

@@ -94,7 +94,14 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking));
+  {
+    // its own priority class: streams of one class share a few hardware queues round-robin, and a post-stage stream that
+    // lands on the search stream's queue runs behind it instead of beside it (seen with the third image of a process)
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    if (least != greatest) HIP_CHECK(hipStreamCreateWithPriority(&tail_stream_, hipStreamNonBlocking, least));
+    else HIP_CHECK(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking));
+  }
   for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if (const char *e = dbg_env("CFR_TAIL_STREAM")) tail_overlap_mode_ = atoi(e) != 0 ? 1 : 0;
   if (const char *e = dbg_env("CFR_TAIL_BLOCKS")) tail_blocks_per_cu_ = atoi(e);
