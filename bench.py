@@ -360,7 +360,7 @@ def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     """One of the other BASELINE configs on the same index: timed steps with resident inputs + a check against the C oracle."""
     paired = mode == "pe"
     k = 5 if paired else 1
-    n = args.reads if paired else 200_000
+    n = args.reads if paired else (200_000 if args.index_gbp else 1_000_000)   # (cfg5's share per GPU is 2.5 M long reads: 9.0e6 reads/s there, 8.8e6 at 1 M, 7.2e6 at 200 k - chains per lane)
     cat = np.load(os.path.join(cache, "genome_cat.npy"), mmap_mode="r")
     starts = np.load(os.path.join(cache, "genome_starts.npy"))
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)       # (reads first, image second: see main)
@@ -504,7 +504,7 @@ def main():
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
     longmode = args.mode == "long"
     if longmode and args.reads == 10_000_000:
-        args.reads = 200_000
+        args.reads = 200_000 if args.index_gbp else 1_000_000
     if longmode and args.cpu_sample == 2_000_000:
         args.cpu_sample = 20_000
     if longmode and args.count_sample == 200_000:
