@@ -323,11 +323,13 @@ def strains_config(torch, capi, ora, args, device):
     idx = capi.Index(prefix, capi.default_params(max_result=1))
     dev = capi.DeviceIndex(idx, device.index or 0)
     total = n * args.read_len
-    res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
-    mat_pin = capi.PinnedArray(n, capi.MATCH_DTYPE)
+    compact = args.results == "compact"
+    res_pin = capi.PinnedArray(n, capi.RESULT_COMPACT_DTYPE if compact else capi.RESULT_DTYPE)
+    mat_pin = capi.PinnedArray(n, capi.MATCH_COMPACT_DTYPE if compact else capi.MATCH_DTYPE)
 
     def step():
-        return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
+        f = dev.classify_resident_compact if compact else dev.classify_resident
+        return f(reads_d.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
     step()          # (the scratch pool of the single-lane folds grows on the way, and the library picks its schedule - post stage
     step()          #  beside the next search or behind it - from what the previous call saw: two untimed steps)
     torch.cuda.synchronize()
@@ -343,11 +345,11 @@ def strains_config(torch, capi, ora, args, device):
     offs_h = (np.arange(nchk + 1, dtype=np.uint64) * np.uint64(args.read_len))
     oo = ora.OracleIndex(prefix, max_result=1)
     ores = oo.classify(b1, offs_h, dust=False, threads=min(os.cpu_count() or 1, 64))
-    res, mat = res_pin.array, mat_pin.array
+    res, mat = capi.expand_compact(res_pin.array[:nchk], mat_pin.array[:nchk], 1) if compact else (res_pin.array, mat_pin.array)
     same = all(idx.format_tsv("r", res[i], mat) == oo.format("r", ores[i]) for i in range(nchk))
     out = {"value": n * steps / el, "unit": "reads/s", "ms_per_step": 1000 * el / steps, "steps": steps,
            "workload": f"{idx.info().n/1e9:.2f} Gbp index of 25 species x 20 strains 0.1 % apart, {n} x {args.read_len} bp SE reads, -k 1, inputs resident in HBM",
-           "search_ms": st.search_ms, "tail_ms": st.tail_ms, "classified_fraction": float((res["n_match"] > 0).mean()),
+           "search_ms": st.search_ms, "tail_ms": st.tail_ms, "classified_fraction": float((res_pin.array["n_match"] > 0).mean()),
            "tsv_lines_equal_oracle_on_first": nchk, "equals_oracle": bool(same)}
     oo.close()
     res_pin.free()
@@ -377,13 +379,15 @@ def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     dev = capi.DeviceIndex(idx, device.index or 0)
     offs_h = offs_d.cpu().numpy().astype(np.uint64)
     total = int(offs_h[-1])
-    res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
-    mat_pin = capi.PinnedArray(n * k, capi.MATCH_DTYPE)
+    compact = args.results == "compact"
+    res_pin = capi.PinnedArray(n, capi.RESULT_COMPACT_DTYPE if compact else capi.RESULT_DTYPE)
+    mat_pin = capi.PinnedArray(n * k, capi.MATCH_COMPACT_DTYPE if compact else capi.MATCH_DTYPE)
 
     def step():
+        f = dev.classify_resident_compact if compact else dev.classify_resident
         if paired:
-            return dev.classify_resident(r1.data_ptr(), offs_d.data_ptr(), n, total, r2.data_ptr(), offs_d.data_ptr(), total, results=res_pin.array, matches=mat_pin.array)
-        return dev.classify_resident(r1.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
+            return f(r1.data_ptr(), offs_d.data_ptr(), n, total, r2.data_ptr(), offs_d.data_ptr(), total, results=res_pin.array, matches=mat_pin.array)
+        return f(r1.data_ptr(), offs_d.data_ptr(), n, total, results=res_pin.array, matches=mat_pin.array)
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -400,13 +404,14 @@ def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     b2 = r2.reshape(-1)[:hi].cpu().numpy() if paired else None
     oo = ora.OracleIndex(prefix, max_result=k)
     ores = oo.classify(b1, offs_h[:nchk + 1].copy(), b2, offs_h[:nchk + 1].copy() if paired else None, dust=False, threads=min(os.cpu_count() or 1, 64))
-    res = res_pin.array
+    res = capi.expand_compact(res_pin.array[:nchk], mat_pin.array[:nchk * k], k)[0] if compact else res_pin.array
     same = all((int(res[i]["score"]), int(res[i]["secondary_score"]), int(res[i]["hit_length"]), int(res[i]["n_match"])) ==
                (ores[i].score, ores[i].secondaryScore, ores[i].hitLength, ores[i].nmatch) for i in range(nchk))
     out = {"value": n * steps / el, "unit": "read pairs/s" if paired else "reads/s", "ms_per_step": 1000 * el / steps, "steps": steps,
            "workload": (f"{n} x 2x{args.read_len} bp pairs, insert 250-500, -k 5 (BASELINE configs[2])" if paired else
                         f"{n} long reads, 5-20 kbp (mean {total / n:.0f} bp), 3% del / 3% ins / 4% sub (BASELINE configs[4]-style reads on this index)"),
-           "bases_per_s": total * steps / el, "search_ms": st.search_ms, "classified_fraction": float((res["n_match"] > 0).mean()),
+           "bases_per_s": total * steps / el, "search_ms": st.search_ms, "classified_fraction": float((res_pin.array["n_match"] > 0).mean()),
+           "entry": "cfr_classify_batch_resident_compact" if compact else "cfr_classify_batch_resident",
            "equals_oracle_on_first": nchk, "equals_oracle": bool(same)}
     res_pin.free()
     mat_pin.free()
@@ -441,6 +446,9 @@ def main():
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
                          "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")
     ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
+    ap.add_argument("--results", choices=["compact", "wide"], default="compact",
+                    help="result layout of the timed entry: compact = cfr_classify_batch_resident_compact (20 + 12 bytes per read / match slot "
+                         "cross PCIe), wide = cfr_classify_batch_resident (40 + 24); the other one is reported under other_result_layout")
     ap.add_argument("--workload", choices=["cfg2", "strains20"], default="cfg2",
                     help="cfg2 = the metric's index (50 species x 5 strains 1 %% apart); strains20 = the data-sensitivity case: "
                          "25 species x 20 strains 0.1 %% apart x 2 Mbp (ranges of ~20 rows per hit: wide text mode, team fold)")
@@ -537,12 +545,25 @@ def main():
     res_pin = capi.PinnedArray(args.reads, capi.RESULT_DTYPE)     # cfr_host_alloc: D2H at PCIe rate
     mat_pin = capi.PinnedArray(args.reads * k, capi.MATCH_DTYPE)
     results, matches = res_pin.array, mat_pin.array
+    # the timed entry: cfr_classify_batch_resident_compact (same results, 20 + 12 bytes per read / match slot instead of
+    # 40 + 24: the step's D2H halves) unless --results wide; the other one is timed as a sub-result
+    entry = {"compact": args.results == "compact"}
+    cres_pin = capi.PinnedArray(args.reads, capi.RESULT_COMPACT_DTYPE)
+    cmat_pin = capi.PinnedArray(args.reads * k, capi.MATCH_COMPACT_DTYPE)
 
     def step():
+        f = dev.classify_resident_compact if entry["compact"] else dev.classify_resident
+        r, m = (cres_pin.array, cmat_pin.array) if entry["compact"] else (results, matches)
         if paired:
-            return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, reads2_d.data_ptr(),
-                                         offs_d.data_ptr(), total_bases, results=results, matches=matches)
-        return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, results=results, matches=matches)
+            return f(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, reads2_d.data_ptr(), offs_d.data_ptr(), total_bases, results=r, matches=m)
+        return f(reads_d.data_ptr(), offs_d.data_ptr(), args.reads, total_bases, results=r, matches=m)
+
+    def widen():
+        """the wide arrays every check below reads, from what the timed entry delivered"""
+        if entry["compact"]:
+            r, m = capi.expand_compact(cres_pin.array, cmat_pin.array, k)
+            results[:] = r
+            matches[:len(m)] = m
 
     for _ in range(args.warmup):
         step()
@@ -560,6 +581,7 @@ def main():
     elapsed = time.perf_counter() - t0
     from centrifuger_amd import shard
     elapsed = shard.max_over_ranks(elapsed, dist=dist, device=None if share_gpu else device)   # the job is as slow as its slowest rank
+    widen()
     classified = int((results["n_match"] > 0).sum())
     if args.inner:      # run under rocprofv3 by the parent bench: the timed launches are all it is for
         if rank == 0:
@@ -574,7 +596,20 @@ def main():
     torch.cuda.synchronize()
     ms_with_dust = 1000.0 * (time.perf_counter() - t1)
     dev.set_dust(False)
+    # the other result layout, timed alike (sub-result)
+    entry["compact"] = not entry["compact"]
+    step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms_other = 1000.0 * (time.perf_counter() - t1) / args.steps
+    other_is = "compact" if entry["compact"] else "wide"
+    entry["compact"] = not entry["compact"]
     step()                                               # results of the plain step again (the checks below read them)
+    torch.cuda.synchronize()
+    widen()
     os.sched_setaffinity(0, all_cpus)                    # the CPU legs below (oracle counters, reference baseline) get every core back
 
     if rank != 0:
@@ -600,6 +635,10 @@ def main():
                      ("pack_ms", "search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")},
     }
 
+    out["config"]["timed_entry"] = ("cfr_classify_batch_resident_compact (20 + 12 bytes per read / match slot to the host)" if entry["compact"]
+                                    else "cfr_classify_batch_resident (40 + 24 bytes per read / match slot to the host)")
+    out["other_result_layout"] = {"layout": other_is, "value": args.reads * world / (ms_other / 1e3), "unit": out["unit"], "ms_per_step": ms_other,
+                                  "note": "the same step through the other entry (rank 0's own clock): the results are the same fields in the other widths"}
     out["with_device_sdust"] = {"value": args.reads / (ms_with_dust / 1e3), "unit": out["unit"], "ms_per_step": ms_with_dust,
                                 "note": "the same step with the reference's default pre-step (SDUST, CentrifugerClass.cpp:276-316) done on the device: "
                                         "unmasked reads resident in HBM in, private masked copy + k_dust + the step; one process, one step timed"}

@@ -44,9 +44,31 @@ HIT_DTYPE = np.dtype([("sp", "<u8"), ("ep", "<u8"), ("l", "<i4"), ("strand", "<i
 RESULT_DTYPE = np.dtype([("score", "<u8"), ("secondary_score", "<u8"), ("hit_length", "<i4"), ("query_length", "<i4"),
                          ("n_match", "<i4"), ("pad", "<i4"), ("match_begin", "<u8")])
 MATCH_DTYPE = np.dtype([("id", "<u8"), ("taxid", "<u8"), ("kind", "<i4"), ("pad", "<i4")])
+# the narrow layout of cfr_classify_batch_resident_compact (20 + 12 bytes)
+RESULT_COMPACT_DTYPE = np.dtype([("score", "<u4"), ("secondary_score", "<u4"), ("hit_length", "<u4"), ("query_length", "<u4"),
+                                 ("n_match", "u1"), ("flags", "u1"), ("pad", "<u2")])
+MATCH_COMPACT_DTYPE = np.dtype([("id_kind", "<u4"), ("taxid_lo", "<u4"), ("taxid_hi", "<u4")])
+COMPACT_WIDE = 1
+
+
+def expand_compact(cres, cmatch, max_result):
+    """cfr_result_compact / cfr_match_compact arrays -> the wide arrays (RESULT_DTYPE, MATCH_DTYPE) with match_begin = i * max_result.
+    Raises if a read is flagged CFR_COMPACT_WIDE (its values did not fit: use the wide entry for such a batch)."""
+    if (cres["flags"] & COMPACT_WIDE).any():
+        raise ValueError("a read of the batch does not fit the compact result layout (CFR_COMPACT_WIDE)")
+    n = len(cres)
+    res = np.zeros(n, dtype=RESULT_DTYPE)
+    for f in ("score", "secondary_score", "hit_length", "query_length", "n_match"):
+        res[f] = cres[f]
+    res["match_begin"] = np.arange(n, dtype=np.uint64) * np.uint64(max_result)
+    mat = np.zeros(len(cmatch), dtype=MATCH_DTYPE)
+    mat["id"] = cmatch["id_kind"] & np.uint32(0x7fffffff)
+    mat["kind"] = (cmatch["id_kind"] >> np.uint32(31)).astype(np.int32)
+    mat["taxid"] = cmatch["taxid_lo"].astype(np.uint64) | (cmatch["taxid_hi"].astype(np.uint64) << np.uint64(32))
+    return res, mat
 
 EXPORTS = [
-    "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
+    "cfr_classify_batch_resident_compact", "cfr_params_default", "cfr_last_error", "cfr_version", "cfr_index_open", "cfr_index_destroy", "cfr_index_get_info",
     "cfr_device_count", "cfr_device_index_create", "cfr_device_index_create_ex", "cfr_device_options_default",
     "cfr_device_index_destroy", "cfr_device_index_get_info", "cfr_device_index_set_dust", "cfr_dust_mask_device",
     "cfr_dust_mask_batch_literal",
@@ -344,6 +366,23 @@ class DeviceIndex:
                                                C.c_void_p(d_bases2 or None), C.c_void_p(d_offsets2 or None), C.c_size_t(n),
                                                C.c_uint64(total1), C.c_uint64(total2), _p(results), _p(matches),
                                                C.c_size_t(len(matches)), C.byref(nm))
+        _check(st)
+        return results, matches[:nm.value]
+
+    def classify_resident_compact(self, d_bases1: int, d_offsets1: int, n: int, total1: int, d_bases2: int = 0, d_offsets2: int = 0,
+                                  total2: int = 0, results=None, matches=None):
+        """classify_resident with the narrow result layout (RESULT_COMPACT_DTYPE / MATCH_COMPACT_DTYPE arrays; max_result > 0);
+        expand_compact() gives the wide arrays."""
+        k = max(1, self.index.params.max_result)
+        if results is None:
+            results = np.zeros(n, dtype=RESULT_COMPACT_DTYPE)
+        if matches is None:
+            matches = np.zeros(max(16, k * n), dtype=MATCH_COMPACT_DTYPE)
+        nm = C.c_size_t(0)
+        st = lib().cfr_classify_batch_resident_compact(self._d, C.c_void_p(d_bases1), C.c_void_p(d_offsets1),
+                                                       C.c_void_p(d_bases2 or None), C.c_void_p(d_offsets2 or None), C.c_size_t(n),
+                                                       C.c_uint64(total1), C.c_uint64(total2), _p(results), _p(matches),
+                                                       C.c_size_t(len(matches)), C.byref(nm))
         _check(st)
         return results, matches[:nm.value]
 

@@ -201,6 +201,19 @@ cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, c
   });
 }
 
+cfr_status cfr_classify_batch_resident_compact(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1, const void *d_bases2,
+                                               const void *d_offsets2, size_t n, uint64_t total_bases1, uint64_t total_bases2,
+                                               cfr_result_compact *results, cfr_match_compact *matches, size_t match_cap, size_t *n_matches) {
+  if (!d || (n && (!d_bases1 || !d_offsets1 || !results || !matches))) return bad_arg("cfr_classify_batch_resident_compact: null argument");
+  if ((d_bases2 == nullptr) != (d_offsets2 == nullptr)) return bad_arg("cfr_classify_batch_resident_compact: mate buffers must both be given");
+  return guarded([&]() -> cfr_status {
+    d->d->classify_device((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
+                          (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, reinterpret_cast<cfr_result *>(results),
+                          reinterpret_cast<cfr_match *>(matches), match_cap, n_matches, nullptr, /*compact=*/true);
+    return CFR_OK;
+  });
+}
+
 void *cfr_host_alloc(size_t bytes) { return cfr::host_alloc_pinned(bytes); }
 void cfr_host_free(void *p) { cfr::host_free_pinned(p); }
 

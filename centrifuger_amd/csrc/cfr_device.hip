@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -960,7 +960,7 @@ std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool pe
 
 void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
-                                  size_t *match_extent, const HostSrc *src) {
+                                  size_t *match_extent, const HostSrc *src, bool compact) {
   HIP_CHECK(hipSetDevice(device_));
   last_stats = cfr_batch_stats{};
   if (match_extent) *match_extent = 0;
@@ -968,6 +968,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
+  if (compact && !stride) throw HipError{"the compact result layout needs max_result > 0", -2};
+  const size_t res_bytes = compact ? sizeof(cfr_result_compact) : sizeof(cfr_result), match_bytes = compact ? sizeof(cfr_match_compact) : sizeof(cfr_match);
   if (dust_ && !src && !view_.prot.enabled) {          // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
     // reads already on the device (the caller's buffer stays as it is): mask a private copy
     auto masked_copy = [&](size_t slot, const uint8_t *d_b, const uint64_t *d_o, uint64_t total) -> const uint8_t * {
@@ -1028,13 +1030,21 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
                       const void *d_heavy = nullptr, unsigned long long *h_heavy = nullptr) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
+    if (compact) {                          // the narrow layout is made on the device; what is copied out are its arrays
+      cfr_result_compact *c_res = (cfr_result_compact *)scratch(par ? S_CRES1 : S_CRES, std::max(cnt, sb) * sizeof(cfr_result_compact));
+      cfr_match_compact *c_match = (cfr_match_compact *)scratch(par ? S_CMATCH1 : S_CMATCH, (stride * std::max(cnt, sb) + 1) * sizeof(cfr_match_compact));
+      k_compact_results<<<grid_for(cnt), kBlock, 0, st>>>(d_res, d_match, cnt, stride, c_res, c_match);
+      HIP_CHECK(hipGetLastError());
+      d_res = reinterpret_cast<const cfr_result *>(c_res);
+      d_match = reinterpret_cast<const cfr_match *>(c_match);
+    }
     HIP_CHECK(hipEventRecord(ev_[7], st));
     HIP_CHECK(hipEventRecord(tail_done_[par], st));
     HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
     static const bool no_copy = dbg_env("CFR_NO_COPY_OUT") && atoi(dbg_env("CFR_NO_COPY_OUT"));     // diagnosis: the step without its D2H
     if (!no_copy) {
-      HIP_CHECK(hipMemcpyAsync(results + lo, d_res, cnt * sizeof(cfr_result), hipMemcpyDeviceToHost, copy_stream_));
-      if (extent) HIP_CHECK(hipMemcpyAsync(matches + stride * lo, d_match, extent * sizeof(cfr_match), hipMemcpyDeviceToHost, copy_stream_));
+      HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, hipMemcpyDeviceToHost, copy_stream_));
+      if (extent) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, hipMemcpyDeviceToHost, copy_stream_));
     }
     if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
     if (d_heavy) HIP_CHECK(hipMemcpyAsync(h_heavy, d_heavy, 8, hipMemcpyDeviceToHost, copy_stream_));

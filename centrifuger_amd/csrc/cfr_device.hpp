@@ -140,7 +140,7 @@ class DeviceIndex {
   // (fast when that memory came from cfr_host_alloc).  matches: stride entries per read.
   void classify_device(const uint8_t *d_bases1, const uint64_t *d_offs1, const uint8_t *d_bases2, const uint64_t *d_offs2,
                        size_t n, uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
-                       size_t *match_extent, const struct HostSrc *src = nullptr);
+                       size_t *match_extent, const struct HostSrc *src = nullptr, bool compact = false);   // compact: results / matches are cfr_result_compact / cfr_match_compact arrays
   void classify_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2, size_t n,
                      cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent);
 

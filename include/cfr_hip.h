@@ -181,6 +181,28 @@ cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, c
                                        uint64_t total_bases1, uint64_t total_bases2,
                                        cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
 
+/* The same call with the results in a narrow layout: 20 + 12 bytes per read and match slot instead of 40 + 24.  At several
+ * hundred million reads per second the step is co-limited by the device-to-host copy of its results (64 bytes per single-end
+ * read, 160 per pair with -k 5); the fields are the same, in the widths they need for reads below 64 k bases.
+ *   max_result > 0 only; the match slots of read i are [i * max_result, i * max_result + n_match) (no match_begin field).
+ *   A read one of whose values does not fit (score >= 2^32, sequence id >= 2^31 ...) has CFR_COMPACT_WIDE set in `flags`: its
+ *   other fields are not meaningful, cfr_classify_batch_resident gives them. */
+#define CFR_COMPACT_WIDE 1u
+typedef struct {
+  uint32_t score, secondary_score;
+  uint32_t hit_length, query_length;
+  uint8_t n_match, flags;
+  uint16_t pad;
+} cfr_result_compact;                 /* 20 bytes */
+typedef struct {
+  uint32_t id_kind;                   /* bit 31: kind (cfr_match.kind), bits 0..30: id */
+  uint32_t taxid_lo, taxid_hi;        /* ORIGINAL tax id */
+} cfr_match_compact;                  /* 12 bytes */
+cfr_status cfr_classify_batch_resident_compact(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1,
+                                               const void *d_bases2, const void *d_offsets2, size_t n,
+                                               uint64_t total_bases1, uint64_t total_bases2,
+                                               cfr_result_compact *results, cfr_match_compact *matches, size_t match_cap, size_t *n_matches);
+
 /* pinned host memory for result buffers (hipHostMalloc); NULL on failure */
 void *cfr_host_alloc(size_t bytes);
 void cfr_host_free(void *p);

@@ -49,7 +49,7 @@ def world(tmp_path_factory):
     reads = synth.make_reads(g, N_READS, READ_LEN, seed=77, sub_rate=0.01, n_rate=0.001)
     r1, r2 = synth.make_pairs(g, 200_000, 125, seed=78)
     longs = synth.make_long_reads(g, 3000, 2000, 12000, seed=79)
-    return {"prefix": prefix, "reads": reads, "pairs": (r1, r2), "long": longs}
+    return {"prefix": prefix, "reads": reads, "pairs": (r1, r2), "long": longs, "exact70k": np.ascontiguousarray(g.seqs[0][1000:71000])}
 
 
 def _open(prefix, k, env=None):
@@ -249,6 +249,50 @@ def test_families_of_70_strains_team_fold_limits(tmp_path, k):
     for i in range(mp):
         assert idx.format_tsv("r", resp[i], matp) == o.format("r", oresp[i]), i
     o.close()
+
+
+@pytest.mark.parametrize("k", [1, 5])
+def test_resident_entries_wide_and_compact(world, k):
+    """cfr_classify_batch_resident (the entry the bench times) and cfr_classify_batch_resident_compact (the same results in the
+    20 + 12 byte layout) against the host-buffer entry: single-end and pairs, reads of mixed lengths; a long read whose score
+    does not fit 32 bits comes back flagged CFR_COMPACT_WIDE."""
+    import torch
+    idx, dev = _open(world["prefix"], k)
+    dv = torch.device("cuda")
+
+    def up(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(dv)
+    rs = world["reads"]
+    n = 300_000
+    b = rs.bases[:int(rs.offsets[n])]
+    o = rs.offsets[:n + 1]
+    want = digest(*canon(*dev.classify(b, o), k))
+    db, do = up(b, np.uint8), up(o.astype(np.int64), np.int64)
+    torch.cuda.synchronize()
+    res, mat = dev.classify_resident(db.data_ptr(), do.data_ptr(), n, int(o[-1]))
+    assert digest(*canon(res, mat, k)) == want
+    cres, cmat = dev.classify_resident_compact(db.data_ptr(), do.data_ptr(), n, int(o[-1]))
+    assert cres.dtype.itemsize == 20 and cmat.dtype.itemsize == 12
+    assert digest(*canon(*capi.expand_compact(cres, cmat, k), k)) == want
+    r1, r2 = world["pairs"]
+    m = len(r1.offsets) - 1
+    wantp = digest(*canon(*dev.classify(r1.bases, r1.offsets, r2.bases, r2.offsets), k))
+    d1, o1, d2, o2 = up(r1.bases, np.uint8), up(r1.offsets.astype(np.int64), np.int64), up(r2.bases, np.uint8), up(r2.offsets.astype(np.int64), np.int64)
+    torch.cuda.synchronize()
+    cres, cmat = dev.classify_resident_compact(d1.data_ptr(), o1.data_ptr(), m, int(r1.offsets[-1]), d2.data_ptr(), o2.data_ptr(), int(r2.offsets[-1]))
+    assert digest(*canon(*capi.expand_compact(cres, cmat, k), k)) == wantp
+    # a 70 kbp exact copy of the text scores (70000 - 15)^2 > 2^32: flagged, and the wide entry has the value
+    ex = world["exact70k"]
+    L = len(ex)
+    dl, ol = up(ex, np.uint8), up(np.array([0, L], dtype=np.int64), np.int64)
+    torch.cuda.synchronize()
+    cres, cmat = dev.classify_resident_compact(dl.data_ptr(), ol.data_ptr(), 1, L)
+    wres, wmat = dev.classify_resident(dl.data_ptr(), ol.data_ptr(), 1, L)
+    assert int(wres["score"][0]) == (L - 15) ** 2 and int(wres["score"][0]) >> 32
+    assert cres["flags"][0] & capi.COMPACT_WIDE
+    with pytest.raises(ValueError):
+        capi.expand_compact(cres, cmat, k)
+    dev.close()
 
 
 def test_ragged_reads_fuzz_against_oracle(world, tmp_path):
