@@ -130,7 +130,8 @@ def _u64(a):
 class BuildInput(C.Structure):
     _fields_ = [("n_seqs", C.c_uint64), ("seq_names", C.POINTER(C.c_char_p)), ("seq_taxids", C.c_void_p), ("seq_lens", C.c_void_p),
                 ("text", C.c_void_p), ("n_nodes", C.c_uint64), ("node_taxid", C.c_void_p), ("node_parent", C.c_void_p),
-                ("node_rank", C.POINTER(C.c_char_p)), ("n_names", C.c_uint64), ("name_taxid", C.c_void_p), ("name_text", C.POINTER(C.c_char_p))]
+                ("node_rank", C.POINTER(C.c_char_p)), ("n_names", C.c_uint64), ("name_taxid", C.c_void_p), ("name_text", C.POINTER(C.c_char_p)),
+                ("n_genomes", C.c_uint64), ("genome_seq", C.c_void_p), ("genome_lens", C.c_void_p), ("n_extra", C.c_uint64)]
 
 
 class BuildOptions(C.Structure):
@@ -143,9 +144,11 @@ class BuildReport(C.Structure):
                 ("seconds_total", C.c_double), ("rounds", C.c_int32), ("pad", C.c_int32)]
 
 
-def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10, offrate=4, rbbwt_b=0, device=0, threads=0, verbose=False):
+def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10, offrate=4, rbbwt_b=0, device=0, threads=0, verbose=False,
+                genome_seq=None, n_extra=0):
     """cfr_build_index: the native writer (suffix array on the MI355X).  seqs: list of np.uint8 ASCII arrays, or one
-    concatenated array together with `names`-many lengths given as (text, lens)."""
+    concatenated array together with the lengths given as (text, lens).  genome_seq: sequence id (index into names) of every
+    genome of the text in text order when that is not 0, 1, 2, ... over all names; the last n_extra names have no tax id."""
     if isinstance(seqs, tuple):
         text, lens = seqs
         text = np.ascontiguousarray(text, dtype=np.uint8)
@@ -167,6 +170,10 @@ def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10
     inp.seq_taxids = _p(keep[1]); inp.seq_lens = _p(keep[2]); inp.text = _p(keep[3])
     inp.n_nodes = len(nodes); inp.node_taxid = _p(keep[4]); inp.node_parent = _p(keep[5]); inp.node_rank = keep[6]
     inp.n_names = len(tax_names); inp.name_taxid = _p(keep[7]); inp.name_text = keep[8]
+    if genome_seq is not None:
+        keep.append(_u64(np.array(genome_seq, dtype=np.uint64)))
+        inp.n_genomes = len(keep[-1]); inp.genome_seq = _p(keep[-1]); inp.genome_lens = _p(keep[2]); inp.seq_lens = None
+        inp.n_extra = n_extra
     opt = BuildOptions()
     lib().cfr_build_options_default(C.byref(opt))
     opt.ftab_chars, opt.offrate, opt.device, opt.threads, opt.rbbwt_b, opt.verbose = ftab_chars, offrate, device, threads, rbbwt_b, int(verbose)

@@ -242,7 +242,7 @@ void write_taxonomy(const std::string &path, const BuildInput &in) {
     sci[nm.first] = s;
   }
   Out o(path);
-  o.u64(order.size()); o.u64(in.names.size()); o.u64(0);
+  o.u64(order.size()); o.u64(in.taxids.size()); o.u64(in.n_extra);          // _nodeCnt, _seqCnt, _extraSeqCnt
   for (size_t i = 0; i < order.size(); ++i) {
     o.u64(parent_c[i]);
     const uint8_t tail[8] = {(uint8_t)tree[order[i]].second, leaf[i], 0, 0, 0, 0, 0, 0};
@@ -252,9 +252,10 @@ void write_taxonomy(const std::string &path, const BuildInput &in) {
   for (uint64_t tid : order) o.u64(tid);
   for (uint64_t tid : order) { const std::string &s = sci[tid]; o.u64(s.size()); o.raw(s.data(), s.size()); }
   for (uint64_t tid : in.taxids) {
+    // a tax id outside the tree: the reference warns and its MapID::Map (std::map operator[]) hands out compact id 0
     auto it = cid.find(tid);
-    if (it == cid.end()) throw std::runtime_error("index build: tax id " + std::to_string(tid) + " of a sequence is not in the taxonomy tree");
-    o.u64(it->second);
+    if (it == cid.end()) { fprintf(stderr, "WARNING: %llu is not in the taxonomy tree\n", (unsigned long long)tid); o.u64(0); }
+    else o.u64(it->second);
   }
   for (const std::string &nm : in.names) { o.u64(nm.size()); o.raw(nm.data(), nm.size()); }
   o.close();
@@ -270,10 +271,22 @@ void build_index_files(const BuildInput &in, const BuildOptions &opt, const std:
   if (opt.ftab_chars < 1 || opt.ftab_chars > 16) throw std::runtime_error("index build: --ftabchars must be in 1..16");
   if (opt.offrate < 0 || opt.offrate > 16) throw std::runtime_error("index build: --offrate must be in 0..16");
   const size_t G = in.lens.size();
-  if (G == 0 || in.names.size() != G || in.taxids.size() != G) throw std::runtime_error("index build: names / taxids / lengths must have one entry per sequence");
+  if (G == 0 || in.genome_seq.size() != G) throw std::invalid_argument("index build: the text needs at least one genome, with one sequence id and one length each");
+  if (in.names.size() != in.taxids.size() + in.n_extra) throw std::invalid_argument("index build: one tax id per conversion-table sequence, none for the extra names");
+  {
+    std::vector<uint8_t> seen(in.names.size(), 0);
+    for (size_t g = 0; g < G; ++g) {
+      if (in.genome_seq[g] >= in.names.size()) throw std::invalid_argument("index build: a genome's sequence id is outside the name list");
+      if (seen[in.genome_seq[g]]) throw std::invalid_argument("index build: sequence " + in.names[in.genome_seq[g]] + " appears twice in the text");
+      seen[in.genome_seq[g]] = 1;
+      // (Builder.hpp:143-150 filters such a genome with a warning; here the caller does the filtering - the command line does)
+      if (in.lens[g] < (uint64_t)w + 1) throw std::invalid_argument("index build: genome " + in.names[in.genome_seq[g]] + " is shorter than --ftabchars + 1");
+    }
+  }
   std::vector<uint64_t> psum(G + 1, 0);
   for (size_t g = 0; g < G; ++g) psum[g + 1] = psum[g] + in.lens[g];
   const uint64_t n = psum[G];
+  if (n < 64) throw std::invalid_argument("index build: the text must hold at least 64 symbols");
   int threads = opt.threads > 0 ? opt.threads : (int)std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
 
   // (the text must be upper-case ACGT only - SequenceCompactor.hpp:59-84 drops everything else before the text is formed, so does
@@ -292,7 +305,13 @@ void build_index_files(const BuildInput &in, const BuildOptions &opt, const std:
   for (size_t k = 0; k < want.size(); ++k) {
     const uint64_t pos = want[k] + w + 1;
     const uint64_t id = (uint64_t)(std::upper_bound(psum.begin(), psum.end(), pos) - psum.begin()) - 1;
-    sel[sa.rows_of[k]] = id;
+    sel[sa.rows_of[k]] = in.genome_seq[id];
+  }
+  // the device numbered the genomes in text order; the index stores sequence ids (Builder.hpp:27-51: genomeSeqIds[...])
+  {
+    bool identity = true;
+    for (size_t g = 0; g < G; ++g) if (in.genome_seq[g] != g) { identity = false; break; }
+    if (!identity) for (auto &x : sa.sampled_ids) x = (uint32_t)in.genome_seq[x];
   }
   const uint8_t *B = sa.bwt.data();
 
@@ -372,7 +391,7 @@ void build_index_files(const BuildInput &in, const BuildOptions &opt, const std:
     write_alphabet(o, false); write_alphabet(o, false);
     o.raw(C, sizeof(C));
     const uint64_t nsamp = (n + rate - 1) / rate, nk = 1ull << (2 * w);
-    o.u64(n); o.i32(0); o.i32((int32_t)rate); o.u64(nsamp); o.u64(w); o.u64(nk); o.u64(0);   // n, strategy, rate, sample size, ftab width, ftab size, adjustedSA0
+    o.u64(n); o.i32(0); o.i32((int32_t)rate); o.u64(nsamp); o.u64(w); o.u64(nk); o.u64(in.genome_seq[0]);   // n, strategy, rate, sample size, ftab width, ftab size, adjustedSA0 = genomeSeqIds[0]
     uint64_t mx = 0;
     for (uint64_t v : sa.sampled_ids) mx = std::max(mx, v);
     int bits = 1;
@@ -390,7 +409,9 @@ void build_index_files(const BuildInput &in, const BuildOptions &opt, const std:
   write_taxonomy(prefix + ".2.cfr", in);
   {
     Out o(prefix + ".3.cfr");
-    for (size_t g = 0; g < G; ++g) { o.u64(g); o.u64(in.lens[g]); }
+    std::map<uint64_t, uint64_t> by_id;                        // Builder.hpp:300-305: the std::map<seqId, length> in key order
+    for (size_t g = 0; g < G; ++g) by_id[in.genome_seq[g]] = in.lens[g];
+    for (const auto &kv : by_id) { o.u64(kv.first); o.u64(kv.second); }
     o.close();
   }
   {

@@ -33,9 +33,11 @@ void build_sa_products(const uint8_t *text, uint64_t n, int device, uint32_t sam
 
 struct TaxNode { uint64_t taxid, parent; std::string rank; };
 struct BuildInput {
-  std::vector<std::string> names;          // sequence names, conversion-table order = sequence ids
-  std::vector<uint64_t> taxids, lens;      // original tax id and length (ACGT only) of every sequence
-  const uint8_t *text = nullptr;           // the sequences back to back, upper-case ACGT
+  std::vector<std::string> names;          // sequence names, conversion-table order = sequence ids; the last n_extra are extra names (no tax id)
+  std::vector<uint64_t> taxids;            // original tax id of every conversion-table sequence
+  uint64_t n_extra = 0;
+  std::vector<uint64_t> genome_seq, lens;  // the genomes of the text, text order: sequence id and length (ACGT only)
+  const uint8_t *text = nullptr;           // the genomes back to back, upper-case ACGT
   std::vector<TaxNode> nodes;              // nodes.dmp
   std::vector<std::pair<uint64_t, std::string>> tax_names;   // names.dmp, scientific names
 };

@@ -5,6 +5,12 @@
 // --bmax / --dcv / --build-mem steer the reference's blockwise sorter (FMBuilder.hpp:444-811) and have no meaning here
 // (the suffix array is built in HBM): accepted and ignored.  Options of other parts of the builder (--protein,
 // --subset-tax, --concat-tax-genome, --checkpoint, file-level conversion tables) are rejected with a message.
+// Input handling follows Builder::Build (Builder.hpp:108-165) and Taxonomy::ReadSeqNameFile (Taxonomy.hpp:303-368): the text is
+// formed in FASTA order; a conversion table may name sequences the FASTA does not hold (they keep their ids and tax ids in
+// .2.cfr, have no length in .3.cfr); a FASTA sequence the table does not name is added as an extra name with a warning (or
+// skipped under --ignore-uncategorized-genome); a repeated sequence id is taken once; a sequence shorter than --ftabchars + 1
+// after dropping non-ACGT characters is filtered with a warning; a name listed twice in the table gets the lowest common
+// ancestor of its tax ids.
 #include <getopt.h>
 #include <zlib.h>
 
@@ -36,11 +42,12 @@ const char *kUsage =
     "\t--offrate INT: SA/offset is sampled every (2^<int>) BWT chars [4]\n"
     "\t--ftabchars INT: # of chars consumed in initial lookup [10]\n"
     "\t--rbbwt-b INT: block size for run-block compressed BWT. 0 for auto. 1 for no compression [0]\n"
+    "\t--ignore-uncategorized-genome: do not index a sequence that is missing from the conversion table\n"
     "\t--gpu INT: MI355X ordinal that builds the suffix array [0]\n"
     "\t--bmax / --dcv / --build-mem: accepted and ignored (they steer the reference's blockwise sorter)\n"
     "\t-h: print this usage message\n";
 
-enum { O_BMAX = 1000, O_DCV, O_MEM, O_OFFRATE, O_FTAB, O_RBB, O_TREE, O_CONV, O_NAMES, O_GPU, O_UNSUPPORTED };
+enum { O_BMAX = 1000, O_DCV, O_MEM, O_OFFRATE, O_FTAB, O_RBB, O_TREE, O_CONV, O_NAMES, O_GPU, O_IGNORE_UNCAT, O_UNSUPPORTED };
 
 void print_log(const char *fmt, ...) {
   char buffer[1024];
@@ -96,9 +103,10 @@ int main(int argc, char *argv[]) {
       {"taxonomy-tree", required_argument, 0, O_TREE}, {"conversion-table", required_argument, 0, O_CONV}, {"name-table", required_argument, 0, O_NAMES},
       {"gpu", required_argument, 0, O_GPU}, {"subset-tax", required_argument, 0, O_UNSUPPORTED}, {"concat-tax-genome", no_argument, 0, O_UNSUPPORTED},
       {"checkpoint", no_argument, 0, O_UNSUPPORTED}, {"protein", no_argument, 0, O_UNSUPPORTED},
-      {"ignore-uncategorized-genome", no_argument, 0, O_UNSUPPORTED}, {0, 0, 0, 0}};
+      {"ignore-uncategorized-genome", no_argument, 0, O_IGNORE_UNCAT}, {0, 0, 0, 0}};
   std::vector<std::string> fasta;
   std::string out_prefix = "centrifuger", tree, names_dmp, conv;
+  bool ignore_uncategorized = false;
   cfr_build_options opt;
   cfr_build_options_default(&opt);
   opt.verbose = 1;
@@ -131,6 +139,7 @@ int main(int argc, char *argv[]) {
       case O_CONV: conv = optarg; break;
       case O_NAMES: names_dmp = optarg; break;
       case O_GPU: opt.device = atoi(optarg); break;
+      case O_IGNORE_UNCAT: ignore_uncategorized = true; break;
       case O_UNSUPPORTED:
         print_log("ERROR: option --%s belongs to a part of centrifuger-build outside the MI355X writer and is not available in this build.",
                   long_options[option_index].name);
@@ -166,75 +175,123 @@ int main(int argc, char *argv[]) {
     }
     lines.clear();
     if (!read_lines(conv.c_str(), lines)) { print_log("ERROR: cannot open %s", conv.c_str()); return EXIT_FAILURE; }
+    // a name listed with two tax ids keeps their lowest common ancestor (Taxonomy.hpp:327-352): lineages to the root, compared
+    // from the root down; the root itself when even the top nodes differ
+    std::map<uint64_t, uint64_t> parent_of;
+    for (size_t i = 0; i < node_taxid.size(); ++i) parent_of.emplace(node_taxid[i], node_parent[i]);
+    auto lineage = [&](uint64_t t) {
+      std::vector<uint64_t> path;
+      for (size_t guard = 0; guard <= parent_of.size(); ++guard) {
+        path.push_back(t);
+        auto it = parent_of.find(t);
+        if (it == parent_of.end() || it->second == t) break;
+        t = it->second;
+      }
+      return path;
+    };
+    std::map<std::string, size_t> first_at;
     for (const std::string &ln : lines) {
       if (ln.empty() || ln[0] == '#') continue;
       char nm[4096];
       unsigned long long tid;
       if (sscanf(ln.c_str(), "%4095s %llu", nm, &tid) != 2) continue;
-      seq_name.push_back(nm);
-      seq_taxid.push_back(tid);
+      auto it = first_at.find(nm);
+      if (it == first_at.end()) {
+        first_at.emplace(nm, seq_name.size());
+        seq_name.push_back(nm);
+        seq_taxid.push_back(tid);
+      } else {
+        const auto pa = lineage(seq_taxid[it->second]), pb = lineage(tid);
+        long i = (long)pa.size() - 1, j = (long)pb.size() - 1;
+        for (; i >= 0 && j >= 0; --i, --j) if (pa[(size_t)i] != pb[(size_t)j]) break;
+        seq_taxid[it->second] = (i == (long)pa.size() - 1) ? pa.back() : pa[(size_t)i + 1];
+      }
     }
   }
+  const size_t n_table = seq_name.size();
   std::map<std::string, size_t> seq_index;
   for (size_t i = 0; i < seq_name.size(); ++i) seq_index.emplace(seq_name[i], i);
 
   // ---- sequences: FASTA (gz or plain), id = first word of the header; everything that is not an upper-case A,C,G,T is
-  // dropped (SequenceCompactor::Compact, SequenceCompactor.hpp:59-84: no capitalisation, no replacement)
-  std::vector<std::vector<uint8_t>> seqs(seq_name.size());
-  std::vector<char> have(seq_name.size(), 0);
-  for (const std::string &path : fasta) {
-    gzFile fp = gzopen(path.c_str(), "r");
-    if (!fp) { print_log("ERROR: cannot open %s", path.c_str()); return EXIT_FAILURE; }
-    gzbuffer(fp, 1 << 20);
-    std::vector<char> buf(1 << 24);
-    std::vector<uint8_t> *cur = nullptr;
-    std::string header;
-    bool in_header = false, at_line_start = true;
-    int got;
-    while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
-      for (int i = 0; i < got; ++i) {
-        const char ch = buf[(size_t)i];
-        if (in_header) {
-          if (ch == '\n') {
-            in_header = false; at_line_start = true;
-            const size_t e = header.find_first_of(" \t\r");
-            const std::string id = header.substr(0, e);
-            auto it = seq_index.find(id);
-            if (it == seq_index.end()) { print_log("ERROR: sequence %s is not in the conversion table (this writer needs every sequence categorised).", id.c_str()); return EXIT_FAILURE; }
-            if (have[it->second]) { print_log("ERROR: sequence id %s appears twice.", id.c_str()); return EXIT_FAILURE; }
-            have[it->second] = 1;
-            cur = &seqs[it->second];
-          } else header += ch;
-          continue;
-        }
-        if (at_line_start && ch == '>') { in_header = true; header.clear(); continue; }
-        at_line_start = ch == '\n';
-        if (cur && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) cur->push_back((uint8_t)ch);
-      }
-    }
-    gzclose(fp);
-  }
-  uint64_t total = 0;
-  std::vector<uint64_t> lens;
-  for (size_t i = 0; i < seq_name.size(); ++i) {
-    if (!have[i] || seqs[i].size() < (size_t)opt.ftab_chars + 1) {
-      print_log("ERROR: sequence %s of the conversion table is %s (every sequence must be present and longer than --ftabchars in this writer).",
-                seq_name[i].c_str(), have[i] ? "too short" : "missing from the FASTA input");
-      return EXIT_FAILURE;
-    }
-    lens.push_back(seqs[i].size());
-    total += seqs[i].size();
-  }
+  // dropped (SequenceCompactor::Compact, SequenceCompactor.hpp:59-84: no capitalisation, no replacement).  The text follows
+  // the order of the records (Builder.hpp:108-165).
   std::vector<uint8_t> text;
-  text.reserve(total);
-  for (auto &s : seqs) { text.insert(text.end(), s.begin(), s.end()); std::vector<uint8_t>().swap(s); }
-  print_log("Read %lu sequences, %lu bases.", (unsigned long)seq_name.size(), (unsigned long)total);
+  std::vector<uint64_t> genome_seq, genome_lens;
+  std::vector<char> taken;                    // per sequence id: a record with this id is already part of the text
+  taken.assign(seq_name.size(), 0);
+  size_t n_extra = 0;
+  {
+    bool keep = false;                        // the record being read goes into the text
+    size_t cur_id = 0, cur_start = 0;
+    std::string cur_name;
+    auto close_record = [&]() {
+      if (!keep) return;
+      const size_t len = text.size() - cur_start;
+      if (len < (size_t)opt.ftab_chars + 1) {   // a genome too short (Builder.hpp:143-150): filtered, and its id is not taken
+        fprintf(stderr, "WARNING: %s is filtered due to its short length (could be from masker)!\n", cur_name.c_str());
+        text.resize(cur_start);
+      } else {
+        taken[cur_id] = 1;
+        genome_seq.push_back(cur_id);
+        genome_lens.push_back(len);
+      }
+      keep = false;
+    };
+    auto open_record = [&](const std::string &id) {
+      close_record();
+      cur_name = id;
+      auto it = seq_index.find(id);
+      if (it == seq_index.end()) {
+        fprintf(stderr, "WARNING: taxonomy id doesn't exist for %s!\n", id.c_str());
+        if (ignore_uncategorized) return;
+        it = seq_index.emplace(id, seq_name.size()).first;      // Taxonomy::AddExtraSeqName: a new id behind the table's, no tax id
+        seq_name.push_back(id);
+        taken.push_back(0);
+        ++n_extra;
+      } else if (taken[it->second]) return;                       // a repeated sequence id is stored once (Builder.hpp:129-130)
+      keep = true;
+      cur_id = it->second;
+      cur_start = text.size();
+    };
+    for (const std::string &path : fasta) {
+      gzFile fp = gzopen(path.c_str(), "r");
+      if (!fp) { print_log("ERROR: cannot open %s", path.c_str()); return EXIT_FAILURE; }
+      gzbuffer(fp, 1 << 20);
+      std::vector<char> buf(1 << 24);
+      std::string header;
+      bool in_header = false, at_line_start = true;
+      int got;
+      while ((got = gzread(fp, buf.data(), (unsigned)buf.size())) > 0) {
+        for (int i = 0; i < got; ++i) {
+          const char ch = buf[(size_t)i];
+          if (in_header) {
+            if (ch == '\n') {
+              in_header = false; at_line_start = true;
+              open_record(header.substr(0, header.find_first_of(" \t\r")));
+            } else header += ch;
+            continue;
+          }
+          if (at_line_start && ch == '>') { in_header = true; header.clear(); continue; }
+          at_line_start = ch == '\n';
+          if (keep && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) text.push_back((uint8_t)ch);
+        }
+      }
+      if (in_header) open_record(header.substr(0, header.find_first_of(" \t\r")));      // (a file that ends inside a header line)
+      gzclose(fp);
+      close_record();
+    }
+  }
+  if (genome_seq.empty()) { print_log("ERROR: no sequence of the input is long enough to be indexed."); return EXIT_FAILURE; }
+  print_log("Read %lu sequences, %lu bases (%lu names in the conversion table, %lu extra names).", (unsigned long)genome_seq.size(),
+            (unsigned long)text.size(), (unsigned long)n_table, (unsigned long)n_extra);
+  seq_taxid.resize(seq_name.size(), 0);       // (not read for the extra names)
 
   auto cptrs = [](const std::vector<std::string> &v) { std::vector<const char *> p; for (const auto &s : v) p.push_back(s.c_str()); return p; };
   const auto p_seq = cptrs(seq_name), p_rank = cptrs(node_rank), p_names = cptrs(name_text);
   cfr_build_input in;
   memset(&in, 0, sizeof(in));
-  in.n_seqs = seq_name.size(); in.seq_names = p_seq.data(); in.seq_taxids = seq_taxid.data(); in.seq_lens = lens.data(); in.text = text.data();
+  in.n_seqs = seq_name.size(); in.seq_names = p_seq.data(); in.seq_taxids = seq_taxid.data(); in.seq_lens = nullptr; in.text = text.data();
+  in.n_genomes = genome_seq.size(); in.genome_seq = genome_seq.data(); in.genome_lens = genome_lens.data(); in.n_extra = n_extra;
   in.n_nodes = node_taxid.size(); in.node_taxid = node_taxid.data(); in.node_parent = node_parent.data(); in.node_rank = p_rank.data();
   in.n_names = name_taxid.size(); in.name_taxid = name_taxid.data(); in.name_text = p_names.data();
   cfr_build_report rep;

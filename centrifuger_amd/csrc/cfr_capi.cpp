@@ -134,15 +134,23 @@ void cfr_build_options_default(cfr_build_options *o) {
 }
 cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *opt, const char *out_prefix, cfr_build_report *report) {
   if (!in || !out_prefix) return bad_arg("cfr_build_index: null argument");
-  if (!in->n_seqs || !in->seq_names || !in->seq_taxids || !in->seq_lens || !in->text) return bad_arg("cfr_build_index: empty input");
+  if (!in->n_seqs || !in->seq_names || !in->seq_taxids || !in->text) return bad_arg("cfr_build_index: empty input");
+  if (in->n_genomes ? (!in->genome_seq || !in->genome_lens) : !in->seq_lens) return bad_arg("cfr_build_index: genome lengths missing");
+  if (in->n_extra > in->n_seqs || (!in->n_genomes && in->n_extra)) return bad_arg("cfr_build_index: n_extra needs the genome list and cannot exceed n_seqs");
   if ((in->n_nodes && (!in->node_taxid || !in->node_parent || !in->node_rank)) || (in->n_names && (!in->name_taxid || !in->name_text)))
     return bad_arg("cfr_build_index: taxonomy arrays missing");
   return guarded([&]() -> cfr_status {
     cfr::BuildInput bi;
     for (uint64_t i = 0; i < in->n_seqs; ++i) {
       bi.names.emplace_back(in->seq_names[i]);
-      bi.taxids.push_back(in->seq_taxids[i]);
-      bi.lens.push_back(in->seq_lens[i]);
+      if (i < in->n_seqs - in->n_extra) bi.taxids.push_back(in->seq_taxids[i]);
+    }
+    bi.n_extra = in->n_extra;
+    if (in->n_genomes) {
+      bi.genome_seq.assign(in->genome_seq, in->genome_seq + in->n_genomes);
+      bi.lens.assign(in->genome_lens, in->genome_lens + in->n_genomes);
+    } else {
+      for (uint64_t i = 0; i < in->n_seqs; ++i) { bi.genome_seq.push_back(i); bi.lens.push_back(in->seq_lens[i]); }
     }
     bi.text = in->text;
     for (uint64_t i = 0; i < in->n_nodes; ++i) bi.nodes.push_back(cfr::TaxNode{in->node_taxid[i], in->node_parent[i], in->node_rank[i] ? in->node_rank[i] : ""});

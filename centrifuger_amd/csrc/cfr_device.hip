@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_VPOS, S_VPOS1, S_VCTL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -308,56 +308,70 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   view_.secondary_hit_len = h.params.consider_secondary_hit_len;
   view_.secondary_factor = h.params.consider_secondary_score_factor;
   memcpy(view_.rank_num, h.tax.rank_num, sizeof(view_.rank_num));
-  // derived wide ftab (cfr_device.hpp): K chosen so the table stays a small fraction of HBM; CFR_FTABX_WIDTH overrides (0 = off)
+  // ---- derived tables (cfr_device.hpp).  What goes into HBM, in order of worth: the text-mode tables (suffix array + 2-bit
+  // text: 4.25 bytes per row below 2^32 rows, 4.75 above), the derived K-mer table (16-byte entries, or 8-byte entries when
+  // those do not fit beside the text-mode tables: 34 GB instead of 69 GB at K = 16), the locate memo (4 bytes per row; with
+  // a suffix array every row is located through the step function anyway, so the memo only takes what is left over).
   view_.ftabx = nullptr;
   view_.ftabx_width = 0;
+  view_.ftabx_e8 = 0;
+  view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0; view_.vpos = nullptr;
+  memset(&view_.steps, 0, sizeof(view_.steps));
+  uint32_t log4n = 0;
+  while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
+  const bool text_possible = h.n >= 64 && h.n < (1ull << 36) && !layout_rb && !protein;
+  bool text_want = text_possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
+  if (const char *e = dbg_env("CFR_TEXT_MODE")) text_want = text_possible && atoi(e) != 0;
+  const double sa_bytes = (double)h.n * (wide_ ? 4.5 : 4.0), text_tab_bytes = sa_bytes + (double)h.n * 0.25;
+  const double ruler_bytes = (double)(h.n >> kRulerShift) * 24.0;
+  const double batch_reserve = 12e9;                       // buffers of a 10 M-read batch (raw hits, virtual rows, results)
   {
-    // auto: several K-mers per text position (an unmatched strand then ends inside the lookup; measured: 16 beats 15 on a
-    // 1 Gbp index by 7 % of the search kernel), at least 2 characters
-    // wider than the on-disk ftab, at most 16 (68 GB) and never more than a quarter of the free HBM
-    uint32_t log4n = 0;
-    while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
+    size_t free_b = 0, total_b = 0;
+    if (text_want && hipMemGetInfo(&free_b, &total_b) == hipSuccess && text_tab_bytes + ruler_bytes + batch_reserve > 0.97 * (double)free_b) text_want = false;   // no room
+  }
+  {
+    // auto K: several K-mers per text position (an unmatched strand then ends inside the lookup; measured: 16 beats 15 on a
+    // 1 Gbp index by 7 % of the search kernel), at least 2 characters wider than the on-disk ftab, at most 16
     uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 2));
+    bool e8 = false;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      // the text-mode tables (10.25 bytes per row at 5-byte entries, 8.25 at u32) and a locate memo at every row (4 bytes) are
-      // worth more than the last step of K: the table gets what they leave, and never more than a quarter of the free HBM
-      const double text_bytes = (double)h.n * (h.n >= 0xfffffff0ull ? 10.25 : 8.25);
-      const bool text_fits = text_bytes + (double)(h.n >> 3) <= 0.9 * (double)free_b;         // (the same test the text-mode block makes)
-      const double rest = fast_load ? 0.0 : (text_fits ? text_bytes : 0.0) + (double)h.n * 4.0 + 8e9;
-      while (K > view_.ftab_width + 2 && ((16ull << (2 * K)) > free_b / 4 || (double)(16ull << (2 * K)) + rest > (double)free_b)) --K;
+      const double rest = fast_load ? 0.0 : (text_want ? text_tab_bytes + ruler_bytes : (double)h.n * 4.0) + batch_reserve;
+      auto fits = [&](uint32_t k, bool small) { return (double)((small ? 8ull : 16ull) << (2 * k)) + rest <= 0.97 * (double)free_b; };
+      while (K > view_.ftab_width + 2 && !fits(K, false) && !fits(K, true)) --K;
+      e8 = !fits(K, false);
     }
-    if (fast_load || balanced) K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13));      // <= 1 GB
+    if (fast_load || balanced) { K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13)); e8 = false; }     // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
+    if (const char *e = dbg_env("CFR_FTABX_E8")) e8 = atoi(e) != 0;        // test hook: the 8-byte entries on a small index
     if (K > 16) K = 16;
     if (protein) K = 0;                  // derived K-mer table and text mode are nucleotide designs
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
       const uint64_t entries = 1ull << (2 * K);
-      uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2);
-      k_build_ftabx<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, K, d_tab);
+      uint64_t *d_tab = dev_alloc<uint64_t>(entries * (e8 ? 1 : 2) + 2);
+      const unsigned gb = (unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22);
+      if (e8) k_build_ftabx<true><<<gb, 256, 0, stream_>>>(view_, K, d_tab);
+      else k_build_ftabx<false><<<gb, 256, 0, stream_>>>(view_, K, d_tab);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
       view_.ftabx = d_tab;
       view_.ftabx_width = K;
-    } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; }   // optional table: run without it
+      view_.ftabx_e8 = e8 ? 1 : 0;
+    } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; view_.ftabx_e8 = 0; }   // optional table: run without it
   }
   lap("side tables + ftabx");
-  // derived text-mode tables (cfr_device.hpp): SA / ISA / 2-bit text by list ranking; CFR_TEXT_MODE=0 turns it off
-  view_.sa32 = nullptr; view_.isa32 = nullptr; view_.sa40 = nullptr; view_.isa40 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
-  {
-    const bool wide = wide_;                                // rows and text positions no longer fit 32 bits: 5-byte entries
-    const bool possible = h.n >= 64 && h.n < (1ull << 38) && !layout_rb && !protein;
-    bool want = possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
-    if (const char *e = dbg_env("CFR_TEXT_MODE")) want = possible && atoi(e) != 0;
-    const size_t esz = wide ? 5 : 4;
-    size_t free_b = 0, total_b = 0;
-    if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)h.n * (2.0 * esz + 0.25) + (double)(h.n >> 3) > 0.9 * (double)free_b) want = false;   // no room
-    if (want) try {
+  // derived text-mode tables: SA / 2-bit text by list ranking, then the step function of the locate values
+  if (text_want) {
+    uint32_t *d_sa = nullptr;
+    uint64_t *d_text_alloc = nullptr;
+    std::vector<void *> tmp_here;
+    auto talloc = [&](size_t bytes) { void *q = temp_alloc(bytes); tmp_here.push_back(q); return q; };
+    try {
       // list ranking by rulers (cfr_kernels.hip.inc): one ruler every 2^kRulerShift rows + the two ends of the list
       const uint64_t nrulers = ((h.n - 1) >> kRulerShift) + 1, cnt = nrulers + 2;      // + terminal + head of the list
-      uint32_t *nx_a = (uint32_t *)temp_alloc(cnt * 4), *nx_b = (uint32_t *)temp_alloc(cnt * 4);
-      uint64_t *ds_a = (uint64_t *)temp_alloc(cnt * 8), *ds_b = (uint64_t *)temp_alloc(cnt * 8);
+      uint32_t *nx_a = (uint32_t *)talloc(cnt * 4), *nx_b = (uint32_t *)talloc(cnt * 4);
+      uint64_t *ds_a = (uint64_t *)talloc(cnt * 8), *ds_b = (uint64_t *)talloc(cnt * 8);
       const unsigned gr = (unsigned)std::min<uint64_t>((cnt + 255) / 256, (uint64_t)num_cus_ * 32);
       k_ruler_walk<<<gr, 256, 0, stream_>>>(view_, nrulers, nx_a, ds_a);
       HIP_CHECK(hipGetLastError());
@@ -367,41 +381,105 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
         std::swap(ds_a, ds_b);
       }
       HIP_CHECK(hipGetLastError());
-      uint8_t *d_sa = dev_alloc<uint8_t>(h.n * esz + 256), *d_isa = dev_alloc<uint8_t>(h.n * esz + 256);   // + pad: a wide range reads 16 entries past its first row
+      const size_t sa_alloc = (wide_ ? (size_t)((h.n * 36 + 7) / 8) : (size_t)h.n * 4) + 256;   // + pad: a wide range reads 16 entries past its first row
+      {
+        void *q = nullptr;
+        HIP_CHECK(hipMalloc(&q, sa_alloc));
+        d_sa = (uint32_t *)q;
+      }
       const uint64_t twords = (h.n + 31) / 32 + 6;
-      uint64_t *d_text = dev_alloc<uint64_t>(twords) + 2;                                      // 16 bytes of padding in front (see k_search_chains_v2: text_slot)
-      HIP_CHECK(hipMemsetAsync(d_text - 2, 0, twords * 8, stream_));
-      HIP_CHECK(hipMemsetAsync(d_sa + h.n * esz, 0, 256, stream_));
-      HIP_CHECK(hipMemsetAsync(d_isa + h.n * esz, 0, 256, stream_));
-      if (wide) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
-      else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, d_isa, (unsigned long long *)d_text);
+      {
+        void *q = nullptr;
+        HIP_CHECK(hipMalloc(&q, twords * 8));
+        d_text_alloc = (uint64_t *)q;
+      }
+      uint64_t *d_text = d_text_alloc + 2;                                                     // 16 bytes of padding in front (see k_search_chains_v2: text_slot)
+      HIP_CHECK(hipMemsetAsync(d_text_alloc, 0, twords * 8, stream_));
+      if (wide_) HIP_CHECK(hipMemsetAsync(d_sa, 0, sa_alloc, stream_));                         // 36-bit entries are or-ed into place
+      else HIP_CHECK(hipMemsetAsync((char *)d_sa + (size_t)h.n * 4, 0, 256, stream_));
+      if (wide_) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, (unsigned long long *)d_text);
+      else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, (unsigned long long *)d_text);
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
-      temp_free(nx_a); temp_free(nx_b); temp_free(ds_a); temp_free(ds_b);
-      if (wide) { view_.sa40 = d_sa; view_.isa40 = d_isa; }
-      else { view_.sa32 = (const uint32_t *)d_sa; view_.isa32 = (const uint32_t *)d_isa; }
+      for (void *q : tmp_here) temp_free(q);
+      tmp_here.clear();
+      if (wide_) view_.sa36 = d_sa; else view_.sa32 = d_sa;
+      lap("SA / text (list ranking)");
+      // ---- the step function: breakpoints = position 0 and the selectedSA positions, runs of equal values merged
+      const uint64_t nsel = h.selected_rows.size();
+      std::vector<uint64_t> bpos(nsel + 1, 0);
+      if (nsel) {
+        uint64_t *d_p = (uint64_t *)talloc(nsel * 8);
+        k_gather_sa<<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(bpos.data() + 1, d_p, nsel * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+      }
+      std::vector<std::pair<uint64_t, uint64_t>> bp;
+      bp.emplace_back(0, h.adjusted_sa0);
+      for (uint64_t g = 0; g < nsel; ++g) if (h.selected_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], h.selected_vals[g]);
+      std::sort(bp.begin(), bp.end());
+      std::vector<uint64_t> spos, sval;
+      for (const auto &e : bp) if (spos.empty() || e.second != sval.back()) { spos.push_back(e.first); sval.push_back(e.second); }
+      uint32_t shift = 0;                                  // ~4 buckets per breakpoint, 2^10 .. 2^22 buckets
+      {
+        const uint64_t want_b = std::min<uint64_t>(std::max<uint64_t>(4 * spos.size(), 1ull << 10), 1ull << 22);
+        while (shift < 40 && ((h.n - 1) >> shift) + 1 > want_b) ++shift;
+      }
+      const uint64_t nb = ((h.n - 1) >> shift) + 2;
+      std::vector<uint32_t> bucket(nb + 1, 0);
+      {
+        uint64_t j = 0;
+        for (uint64_t bkt = 0; bkt <= nb; ++bkt) {         // last breakpoint with pos <= bkt << shift
+          const uint64_t start = bkt << shift;
+          while (j + 1 < spos.size() && spos[j + 1] <= start) ++j;
+          bucket[bkt] = (uint32_t)j;
+        }
+      }
+      StepView S;
+      S.pos = upload(spos); S.val = upload(sval); S.bucket = upload(bucket);
+      S.cnt = spos.size(); S.n = h.n; S.shift = shift;
+      view_.steps = S;
+      unsigned long long *d_bad = (unsigned long long *)talloc(8), bad = 0;
+      HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, stream_));
+      const uint64_t nsamp = (h.n + h.sample_rate - 1) / h.sample_rate;
+      k_memo_check<<<(unsigned)std::min<uint64_t>((nsamp + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, nsamp, d_bad);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      for (void *q : tmp_here) temp_free(q);
+      tmp_here.clear();
+      if (bad || (dbg_env("CFR_STEPS_OFF") && atoi(dbg_env("CFR_STEPS_OFF")))) throw HipError{"the sampled rows do not follow the step function of the selectedSA positions", -5};
+      owned_.push_back(d_sa); device_bytes_ += sa_alloc;
+      owned_.push_back(d_text_alloc); device_bytes_ += twords * 8;
       view_.text2 = d_text;
-      uint32_t log4n = 0;
-      while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
       view_.text_min_l = log4n + 2;                       // random matches rarely get past log4(n) characters
       if (const char *e = dbg_env("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
-    } catch (const HipError &) {                           // optional tables: run without them (what was allocated stays owned and is freed with the image)
+      lap("locate step function");
+    } catch (const HipError &) {                           // optional tables: run without them, and give back what they took
       (void)hipGetLastError();
-      view_.sa32 = nullptr; view_.isa32 = nullptr; view_.sa40 = nullptr; view_.isa40 = nullptr; view_.text2 = nullptr;
+      (void)hipStreamSynchronize(stream_);
+      for (void *q : tmp_here) temp_free(q);
+      if (d_sa) (void)hipFree(d_sa);
+      if (d_text_alloc) (void)hipFree(d_text_alloc);
+      view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
+      memset(&view_.steps, 0, sizeof(view_.steps));       // (the three small step arrays stay owned until the image goes)
     }
   }
-  lap("SA / ISA / text (list ranking)");
-  // derived locate memo (cfr_device.hpp): densest power-of-two rate whose table fits CFR_LOC_MEMO_GB (default 16 GB; 0 = off)
+  // derived locate memo (cfr_device.hpp).  With a suffix array it is a convenience (one gather instead of a gather plus a short
+  // search in cached tables) and only takes memory nobody else wants; without one (protein, fast-load, no room for the text-mode
+  // tables) it is what keeps the locate walks short: densest power-of-two rate whose table fits the budget (0 = off).
   view_.loc_memo = nullptr;
   view_.memo_shift = 0;
   {
-    // default budget: a memo at every row when 60 % of what is still free holds it (4 bytes per row), at least 16 GB worth
+    const bool have_sa_now = have_sa();
     double budget_gb = opt.loc_memo_gb;
     if (budget_gb < 0) {
       budget_gb = fast_load ? 0.0 : 16.0;
       size_t free_b = 0, total_b = 0;
-      // everything still free but 16 GB for the batch buffers: a memo at every row (4 bytes) is what makes the one-launch tail possible
-      if (!fast_load && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_gb = std::max(budget_gb, ((double)free_b - 16e9) / 1e9);
+      // everything still free but the batch buffers
+      if (!fast_load && hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget_gb = std::max(have_sa_now ? 0.0 : budget_gb, ((double)free_b - 16e9) / 1e9);
+      if (have_sa_now && (double)h.n * 4.0 > budget_gb * 1e9) budget_gb = 0;      // all rows or nothing: the step function serves the rest
     }
     if (const char *e = dbg_env("CFR_LOC_MEMO_GB")) budget_gb = atof(e);
     uint64_t max_val = h.adjusted_sa0;
@@ -414,54 +492,12 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       const uint64_t entries = ((h.n - 1) >> shift) + 1;
       uint32_t *d_memo = dev_alloc<uint32_t>(entries);
       const unsigned gm = (unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 20);
-      bool filled = false;
-      const bool have_sa = wide_ ? view_.sa40 != nullptr : view_.sa32 != nullptr;
-      if (have_sa && !protein && !(dbg_env("CFR_MEMO_WALK") && atoi(dbg_env("CFR_MEMO_WALK")))) {
-        // from the text order (cfr_kernels.hip.inc, memo_step_value): breakpoints = position 0 and the selectedSA positions
-        const uint64_t nsel = h.selected_rows.size();
-        std::vector<uint64_t> bpos(nsel + 1, 0), bval(nsel + 1, 0);
-        if (nsel) {
-          uint64_t *d_p = (uint64_t *)temp_alloc(nsel * 8);
-          if (wide_) k_gather_sa<true><<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
-          else k_gather_sa<false><<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
-          HIP_CHECK(hipGetLastError());
-          HIP_CHECK(hipMemcpyAsync(bpos.data() + 1, d_p, nsel * 8, hipMemcpyDeviceToHost, stream_));
-          HIP_CHECK(hipStreamSynchronize(stream_));
-          temp_free(d_p);
-        }
-        std::vector<std::pair<uint64_t, uint64_t>> bp;
-        bp.emplace_back(0, h.adjusted_sa0);
-        for (uint64_t g = 0; g < nsel; ++g) if (h.selected_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], h.selected_vals[g]);
-        std::sort(bp.begin(), bp.end());
-        for (size_t g = 0; g < bp.size(); ++g) { bpos[g] = bp[g].first; bval[g] = bp[g].second; }
-        bpos.resize(bp.size()); bval.resize(bp.size());
-        uint64_t *d_bp = (uint64_t *)temp_alloc(bp.size() * 8), *d_bv = (uint64_t *)temp_alloc(bp.size() * 8);
-        unsigned long long *d_bad = (unsigned long long *)temp_alloc(8), bad = 0;
-        HIP_CHECK(hipMemcpyAsync(d_bp, bpos.data(), bp.size() * 8, hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipMemcpyAsync(d_bv, bval.data(), bp.size() * 8, hipMemcpyHostToDevice, stream_));
-        HIP_CHECK(hipMemsetAsync(d_bad, 0, 8, stream_));
-        const MemoSteps S{d_bp, d_bv, (uint64_t)bp.size()};
-        const uint64_t nsamp = (h.n + h.sample_rate - 1) / h.sample_rate;
-        const unsigned gs = (unsigned)std::min<uint64_t>((nsamp + 255) / 256, 1u << 20);
-        if (wide_) k_memo_check<true><<<gs, 256, 0, stream_>>>(view_, S, nsamp, d_bad);
-        else k_memo_check<false><<<gs, 256, 0, stream_>>>(view_, S, nsamp, d_bad);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, stream_));
-        HIP_CHECK(hipStreamSynchronize(stream_));
-        if (bad == 0) {
-          if (wide_) k_memo_fill<true><<<gm, 256, 0, stream_>>>(view_, S, shift, entries, d_memo);
-          else k_memo_fill<false><<<gm, 256, 0, stream_>>>(view_, S, shift, entries, d_memo);
-          HIP_CHECK(hipGetLastError());
-          HIP_CHECK(hipStreamSynchronize(stream_));
-          filled = true;
-        }
-        temp_free(d_bp); temp_free(d_bv); temp_free(d_bad);
-      }
-      if (!filled) {
-        k_build_loc_memo<<<gm, 256, 0, stream_>>>(view_, shift, entries, d_memo);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipStreamSynchronize(stream_));
-      }
+      if (have_sa_now && view_.steps.pos && !(dbg_env("CFR_MEMO_WALK") && atoi(dbg_env("CFR_MEMO_WALK"))))
+        k_memo_fill<<<gm, 256, 0, stream_>>>(view_, shift, entries, d_memo);      // from the text order: one SA read and a short search per row
+      else
+        k_build_loc_memo<<<gm, 256, 0, stream_>>>(view_, shift, entries, d_memo); // the plain LF walk per row
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
       view_.loc_memo = d_memo;
       view_.memo_shift = shift;
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
@@ -568,13 +604,12 @@ void DeviceIndex::selfcheck(uint64_t out[6]) {
   unsigned long long *d_bad = (unsigned long long *)scratch(S_P0, 4 * 8), h_bad[4];
   HIP_CHECK(hipMemsetAsync(d_bad, 0, 4 * 8, stream_));
   const unsigned g = (unsigned)std::min<uint64_t>((view_.n + 255) / 256, (uint64_t)num_cus_ * 32);
-  if (wide_) k_selfcheck<true><<<g, 256, 0, stream_>>>(view_, d_bad);
-  else k_selfcheck<false><<<g, 256, 0, stream_>>>(view_, d_bad);
+  k_selfcheck<<<g, 256, 0, stream_>>>(view_, d_bad);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipMemcpyAsync(h_bad, d_bad, 4 * 8, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
   for (int k = 0; k < 4; ++k) out[k] = h_bad[k];
-  out[4] = (wide_ ? view_.sa40 != nullptr : view_.sa32 != nullptr) ? 1 : 0;      // text-mode tables present
+  out[4] = have_sa() ? 1 : 0;                                                    // text-mode tables present
   out[5] = view_.loc_memo ? 1 + view_.memo_shift : 0;                            // locate memo present (1 + log2 of its row rate)
 }
 
@@ -618,7 +653,7 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 // size the dense arrays; everything else stays on the device.  Two halves: launch_search (caps, scan, the search kernel)
 // is also what the one-launch post stage of classify_device follows; launch_post is everything behind the search kernel.
 DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                                  uint64_t total1, uint64_t total2, int par) {
+                                                  uint64_t total1, uint64_t total2, int par, bool row_space_only, unsigned long long *vctl) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -634,9 +669,22 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   uint32_t *chain_cnt = (uint32_t *)scratch(par ? S_CHAINCNT1 : S_CHAINCNT, nchains * 4);
   size_t tmp_bytes = scan_tmp_bytes(n);
   void *tmp = scratch(par ? S_SCAN1 : S_SCAN, tmp_bytes);
+  // text-space hits (k_search_chains_v2): four text positions per raw hit slot, and a pool behind them for hits of more rows
+  const bool text_hits = !search_v1_ && !row_space_only && have_sa() && view_.steps.pos && view_.text2;
+  uint64_t *vpos = nullptr;
+  if (text_hits) {
+    if (!vpool_cap_) {
+      vpool_cap_ = std::max<uint64_t>(cap_total, 1ull << 16);
+      if (const char *e = dbg_env("CFR_VPOOL_INIT")) vpool_cap_ = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // test hook: first size (grows on overflow)
+    }
+    if (const char *e = dbg_env("CFR_VPOOL_CAP")) vpool_cap_ = strtoull(e, nullptr, 10);                               // test hook: fixed size (no growth)
+    vpos = (uint64_t *)scratch(par ? S_VPOS1 : S_VPOS, (4 * cap_total + vpool_cap_ + 4) * 8);
+    if (!vctl) vctl = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8);
+  }
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
   HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
+  if (text_hits) HIP_CHECK(hipMemsetAsync(vctl, 0, 16, stream_));
   k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
   exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[1], stream_));
@@ -662,7 +710,9 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.n = view_.n; sv.first_isa = view_.first_isa;
     for (int c = 0; c < 4; ++c) sv.C[c] = view_.C[c];
     sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
-    sv.sa32 = view_.sa32; sv.isa32 = view_.isa32; sv.sa40 = view_.sa40; sv.isa40 = view_.isa40;
+    sv.sa = text_hits ? (wide_ ? view_.sa36 : view_.sa32) : nullptr;
+    sv.ftabx_e8 = view_.ftabx_e8;
+    sv.vpos = vpos; sv.vpool_base = 4 * cap_total; sv.vpool_cap = vpool_cap_; sv.vctl = vctl;
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
@@ -676,7 +726,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
       k_search_chains_v2<2, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt, d_prof);
       HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 16 * 8, hipMemcpyDeviceToHost, stream_));
       HIP_CHECK(hipStreamSynchronize(stream_));
-      static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "isa", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
+      static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "text_hits", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
@@ -690,7 +740,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
-  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total, vpos};
 }
 
 // Translated search (Classifier::TranslatedSearch): 6 chains per mate (strand x frame), one lane each
@@ -715,7 +765,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   else k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
-  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total, nullptr};
 }
 
 void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
@@ -756,7 +806,7 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
     HIP_CHECK(hipEventRecord(ev_[4], st));
     HIP_CHECK(hipEventRecord(ev_[5], st));
     HIP_CHECK(hipEventRecord(ev_[6], st));
-    p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f};
+    p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f, sb.vpos};
     last_stats.n_chains += nchains;
     last_stats.n_rows += nrows_f;
     return;
@@ -792,13 +842,13 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
     if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, st>>>(view_, nhits, hits, row_off, rows);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev_[5], st));
-    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, st>>>(view_, rows, nrows, vals, nullptr);
+    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, st>>>(view_with(sb.vpos), rows, nrows, vals, nullptr);
     HIP_CHECK(hipGetLastError());
   } else {
     HIP_CHECK(hipEventRecord(ev_[5], st));
   }
   HIP_CHECK(hipEventRecord(ev_[6], st));
-  p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows};
+  p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows, sb.vpos};
   last_stats.n_chains += nchains;
   last_stats.n_hits += nhits;
   last_stats.n_rows += nrows;
@@ -807,8 +857,22 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
 
 void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                     uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
-                                    bool fused) {
-  const SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2);
+                                    bool fused, bool row_space_only) {
+  SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0, row_space_only);
+  if (sb.vpos) {
+    // the pool of virtual rows may run dry (many hits of more than 4 rows): this form has a host round trip anyway, so the
+    // flag is read here and the search repeated with a larger pool - and without text-space hits when that is not enough
+    unsigned long long *vctl = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8), h_ctl[2] = {0, 0};
+    for (int attempt = 0;; ++attempt) {
+      HIP_CHECK(hipMemcpyAsync(h_ctl, vctl, 16, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      if (!h_ctl[1]) break;
+      const bool give_up = attempt >= 3 || dbg_env("CFR_VPOOL_CAP");
+      if (!give_up) vpool_cap_ *= 4;
+      sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0, give_up);
+      if (give_up) break;
+    }
+  }
   launch_post(sb, d_b1, d_o1, d_b2, d_o2, n, want_rows, p, hit_begin_host, fused, stream_);
 }
 
@@ -907,7 +971,7 @@ void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uin
   if (n == 0) return;
   Pipe p;
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
-  run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, want_rows, p, &out.hit_begin);
+  run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, want_rows, p, &out.hit_begin, false, /*row_space_only=*/true);   // the hits leave with real BWT rows
   out.hits.resize(p.nhits);
   if (p.nhits) HIP_CHECK(hipMemcpyAsync(out.hits.data(), p.hits, p.nhits * sizeof(cfr_hit), hipMemcpyDeviceToHost, stream_));
   if (want_rows) {
@@ -986,7 +1050,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const auto pieces = cut_pieces(n, stride > 0, sb);
   const size_t nsub = pieces.size();
   const bool paired = d_b2 != nullptr;
-  const bool fused = fused_tail_ && view_.loc_memo && view_.memo_shift == 0;     // k_tail answers rows from the memo itself
+  const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
   std::vector<uint8_t> have_piece(nsub, src ? 0 : 1);
@@ -1061,14 +1125,19 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   std::vector<size_t> todo;                 // pieces still to do
   for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
-    uint32_t *ovf = (uint32_t *)pinned((2 + 2 * kMaxSub) * 8) + 4;  // behind the two u64 totals
-    unsigned long long *heavy_h = (unsigned long long *)pinned((2 + 2 * kMaxSub) * 8) + 2 + kMaxSub;   // reads k_tail_heavy folded, per sub-batch
+    unsigned long long *pin = (unsigned long long *)pinned((2 + 4 * kMaxSub) * 8);    // one block: the pointers below stay valid
+    uint32_t *ovf = (uint32_t *)pin + 4;  // behind the two u64 totals
+    unsigned long long *heavy_h = pin + 2 + kMaxSub;   // reads k_tail_heavy folded, per sub-batch
     for (size_t k = 0; k < kMaxSub; ++k) heavy_h[k] = 0;
     if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
     const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
+    unsigned long long *vctl_d = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8);
+    unsigned long long *vctl_h = pin + 2 + 2 * kMaxSub;   // {cursor, overflow} of the virtual-row pool, per sub-batch
     for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
       TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap_ * sizeof(TailEntry));
       uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap_ * 8);
+      for (size_t k = 0; k < 2 * kMaxSub; ++k) vctl_h[k] = 0;
+      HIP_CHECK(hipMemsetAsync(vctl_d, 0, 2 * kMaxSub * 8, stream_));
       for (size_t k : todo) {
         const size_t lo = pieces[k].first, cnt = pieces[k].second;
         ovf[k] = 0;
@@ -1080,7 +1149,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const int par = tail_overlap ? (int)(k & 1) : 0;
         hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
         if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
-        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, par);
+        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, par, false, vctl_d + 2 * k);
+        const DevView vv = view_with(sbuf.vpos);
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
         if (tail_overlap) {
           HIP_CHECK(hipEventRecord(search_done_[par], stream_));
@@ -1095,15 +1165,15 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
         // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
-        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(vv, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                       pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
-        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(vv, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
         if (heavy) {
           const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * (tail_overlap && tail_blocks_per_cu_ ? std::min(5, 2 * tail_blocks_per_cu_) : 5)));
-          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(vv, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
                                                                            (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(vv, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
                                                                     (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
         }
         HIP_CHECK(hipGetLastError());
@@ -1111,6 +1181,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
+      if (have_sa()) HIP_CHECK(hipMemcpyAsync(vctl_h, vctl_d, 2 * kMaxSub * 8, hipMemcpyDeviceToHost, stream_));   // (behind every search of this round)
       HIP_CHECK(hipStreamSynchronize(stream_));
       HIP_CHECK(hipStreamSynchronize(tail_stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
@@ -1121,10 +1192,17 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         heavy_frac_ = (double)hv / (double)n;
       }
       std::vector<size_t> again;
-      for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
+      bool tail_dry = false, vrows_dry = false;
+      for (size_t k : todo) {
+        if (ovf[k]) tail_dry = true;                                      // the post stage's scratch pool ran dry in this sub-batch
+        if (vctl_h[2 * k + 1]) vrows_dry = true;                          // the search's pool of virtual rows did
+        if (ovf[k] || vctl_h[2 * k + 1]) again.push_back(k);
+      }
       todo.swap(again);
-      if (todo.empty() || pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP")) break;
-      pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it
+      if (todo.empty()) break;
+      if ((tail_dry && (pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP"))) || (vrows_dry && dbg_env("CFR_VPOOL_CAP"))) break;
+      if (tail_dry) pool_cap_ = std::min(pool_cap_ * 4, pool_limit);     // kept for the calls that follow: the workload needs it
+      if (vrows_dry) vpool_cap_ *= 4;
     }
   }
   const bool repeated = one_launch && !todo.empty();
@@ -1135,6 +1213,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     ev_ = evs_[k];
     Pipe p;
     run_device_stages(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr, fused);
+    const DevView vv = view_with(p.vpos);
     const uint64_t extent = stride ? stride * cnt : p.nrows;
     if (!stride) {
       if (match_extent) *match_extent = extent;
@@ -1144,9 +1223,9 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     cfr_result *d_res;
     cfr_match *d_match;
     out_buffers(k, extent, d_res, d_match, stream_);
-    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
+    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(vv, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
                                                                   p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
-    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
+    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(vv, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
                                                               p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
     copy_out(k, d_res, d_match, extent, nullptr, nullptr, stream_);

@@ -13,11 +13,16 @@
 //              (l, sp, ep) FMIndex::BackwardSearch reaches after its first K characters (ftab lookup +
 //              K-w extends, including where it stopped).  One 16-byte gather replaces K-w+1 dependent ones.
 //   sampled  : bit-packed seqIds, one per sample_rate rows    (FixedSizeElemArray.hpp:102-105)
-//   sa/isa/text2 : DERIVED at load time (list ranking over the LF permutation by rulers, k_ruler_walk/_jump/_fill):
-//              SA[row], ISA[pos] (u32 entries for n < 2^32, 5-byte entries above) and the 2-bit text.  A BWT range of <= 4 rows is then extended by comparing the read
-//              with the text 32 bases per step (the rows' suffix positions move in lock step), instead of one LF
-//              step per base; the range is mapped back with ISA when the search ends.
-//   loc_memo : DERIVED at load time: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
+//   sa/text2 : DERIVED at load time (list ranking over the LF permutation by rulers, k_ruler_walk/_jump/_fill):
+//              SA[row] (u32 entries for n < 2^32, 36-bit packed entries up to 2^36) and the 2-bit text.  A BWT range of a few rows
+//              is then extended by comparing the read with the text 48 bases per step (the rows' suffix positions move in
+//              lock step), instead of one LF step per base.  A hit found that way is kept in TEXT-POSITION space: its rows
+//              are "virtual rows" (kVirtRow | index into the sub-batch's vpos array, which holds the text position of
+//              every row of the hit), so no inverse suffix array exists anywhere.
+//   steps    : DERIVED at load time: what FMIndex::BackwardToSampledSA returns, as a step function of the TEXT POSITION of
+//              the row it starts from (breakpoints: position 0 and the selectedSA positions; the premise is verified on
+//              every sampled row, k_memo_check).  locate(row) = steps(SA[row]); locate(virtual row) = steps(vpos[..]).
+//   loc_memo : DERIVED at load time when HBM allows: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
 //              (memo_rate = 1 when n*4 bytes fit the budget).  The LF-walk from row i passes through the same rows
 //              as the reference's, so stopping at a memoised row returns exactly what the full walk would.
 //   sel_rows / sel_vals : sorted selectedSA pairs             (FMIndex.hpp:34)
@@ -61,6 +66,17 @@ struct ProtView {
   char list[32];             // code -> character
 };
 
+// rows >= kVirtRow are virtual: row & ~kVirtRow indexes the sub-batch's vpos array (text position of that row of a hit)
+constexpr uint64_t kVirtRow = 1ull << 63;
+
+// BackwardToSampledSA as a step function of the text position (see cfr_kernels.hip.inc, steps_value)
+struct StepView {
+  const uint64_t *pos, *val;   // breakpoints by ascending text position, pos[0] = 0 ; nullptr = not available
+  const uint32_t *bucket;      // bucket[b] = index of the last breakpoint with pos <= (b << shift)
+  uint64_t cnt, n;
+  uint32_t shift;
+};
+
 struct DevView {            // passed by value to kernels
   uint64_t n, first_isa, adjusted_sa0;
   uint64_t C[5];
@@ -68,15 +84,17 @@ struct DevView {            // passed by value to kernels
   ProtView prot;            // protein image (alternative to both)
   const uint64_t *occ;      // 8 u64 per record
   const uint64_t *ftab;     // 2 u64 per entry
-  const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l); nullptr = off
+  const uint64_t *ftabx;    // derived wide ftab: 2 u64 per K-mer = (sp, (count << 8) | l), or ONE u64 (ftabx_e8, see ftabx8_encode); nullptr = off
   uint32_t ftabx_width;     // K (> ftab_width)
+  uint32_t ftabx_e8;        // 1: 8-byte entries
   const uint64_t *sampled;
   const uint32_t *loc_memo; // derived: memo[j / memo_rate] = BackwardToSampledSA(j) for j % memo_rate == 0; nullptr = off
   uint32_t memo_shift;      // log2(memo_rate)
-  // derived text-mode tables: suffix array, its inverse (u32 entries when n < 2^32, 5-byte entries otherwise), and the
-  // 2-bit text; nullptr = off
-  const uint32_t *sa32, *isa32;
-  const uint8_t *sa40, *isa40;
+  // derived text-mode tables: suffix array (u32 entries when n < 2^32, 36-bit packed entries otherwise) and the 2-bit text; nullptr = off
+  const uint32_t *sa32;
+  const uint32_t *sa36;     // entry i at bits [36 i, 36 i + 36) of the little-endian bit string
+  StepView steps;           // locate as a function of the text position
+  const uint64_t *vpos;     // per launch: text positions behind the virtual rows of this sub-batch's hits
   const uint64_t *text2;    // symbol p at bits 2(p%32) of word p/32
   uint32_t text_min_l;      // a search switches to text comparison once it has matched this many characters
   const uint64_t *sel_rows, *sel_vals;
@@ -166,13 +184,18 @@ class DeviceIndex {
   struct Staged { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; uint64_t t1, t2; };
   Staged stage_inputs(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n);
   // device stages shared by run_batch / classify_device; returns (nhits, nrows) and leaves device pointers in p_
-  struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; };
+  struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; const uint64_t *vpos; };
   void run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                          uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
-                         bool fused = false);
-  struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
+                         bool fused = false, bool row_space_only = false);
+  struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; uint64_t *vpos; };
+  // row_space_only: no text mode (every hit carries real BWT rows); vctl: {pool cursor, overflow flag} of the virtual-row pool
   SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                          uint64_t total1, uint64_t total2, int par = 0);
+                          uint64_t total1, uint64_t total2, int par = 0, bool row_space_only = false, unsigned long long *vctl = nullptr);
+  DevView view_with(const uint64_t *vpos) const { DevView v = view_; v.vpos = vpos; return v; }
+  bool have_sa() const { return view_.sa32 != nullptr || view_.sa36 != nullptr; }
+  // every row (real or virtual) of a hit can be located by one table access: memo at every row, or SA + step function
+  bool locate_direct() const { return (view_.loc_memo && view_.memo_shift == 0) || (have_sa() && view_.steps.pos); }
   SearchBuf launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
@@ -183,7 +206,7 @@ class DeviceIndex {
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
   void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true);
-  bool one_launch_ready() const { return fused_tail_ && fused_post_ && view_.loc_memo && view_.memo_shift == 0 && !view_.prot.enabled; }
+  bool one_launch_ready() const { return fused_tail_ && fused_post_ && locate_direct() && !view_.prot.enabled; }
 
   const HostIndex *host_;
   int device_;
@@ -207,7 +230,8 @@ class DeviceIndex {
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false, team_tail_ = true;
-  bool wide_ = false;                  // n >= 2^32: 5-byte SA / ISA entries and the WIDE search kernel
+  bool wide_ = false;                  // n >= 2^32: 36-bit SA entries and the WIDE search kernel
+  uint64_t vpool_cap_ = 0;             // entries of the virtual-row pool behind the inline part of vpos (hits of more than 4 rows)
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;

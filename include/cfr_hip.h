@@ -253,6 +253,13 @@ typedef struct {
   uint64_t n_names;                 /* names.dmp, scientific names */
   const uint64_t *name_taxid;
   const char *const *name_text;
+  /* Genomes of the text when they are not simply "every sequence, in conversion-table order" (Builder.hpp:108-165: the text
+   * follows the FASTA order, a conversion table may name sequences the FASTA does not hold, and a FASTA sequence the table
+   * does not name is added as an extra name without a tax id).  n_genomes = 0: genome g = sequence g with seq_lens[g]. */
+  uint64_t n_genomes;
+  const uint64_t *genome_seq;       /* sequence id (index into seq_names) of every genome of the text, in text order; no id twice */
+  const uint64_t *genome_lens;      /* their lengths; seq_lens is not read when n_genomes > 0 */
+  uint64_t n_extra;                 /* the LAST n_extra entries of seq_names are extra names (Taxonomy::AddExtraSeqName): seq_taxids not read for them */
 } cfr_build_input;
 typedef struct {
   int32_t ftab_chars;   /* --ftabchars, default 10 */

@@ -138,3 +138,69 @@ def test_native_writer_equals_reference_builder_on_a_fresh_3mbp_text(tmp_path):
             assert na == nb and va == vb, f"field {na} differs"
         assert open(pre + ".2.cfr", "rb").read() == open(ref_prefix + ".2.cfr", "rb").read()
         assert open(pre + ".3.cfr", "rb").read() == open(ref_prefix + ".3.cfr", "rb").read()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref (compiled reference) not present")
+@pytest.mark.parametrize("ignore_uncategorized", [False, True])
+def test_cli_takes_the_inputs_the_reference_builder_takes(tmp_path, ignore_uncategorized):
+    """Builder::Build (Builder.hpp:108-165): FASTA order != conversion-table order, a conversion table naming sequences the FASTA
+    does not hold, a FASTA sequence missing from the table (extra name / skipped), a repeated id, a sequence that is too short
+    after dropping non-ACGT characters, a name listed twice with different tax ids (LCA), a tax id outside the tree: the files of
+    bin/centrifuger-build must equal the reference builder's, and so must a classification on them."""
+    g = synth.make_genomes(n_species=4, n_strains=3, genome_len=30000, seed=17)
+    synth.write_reference_inputs(g, str(tmp_path))
+    rng = np.random.default_rng(5)
+    order = rng.permutation(len(g.names))
+    acgt = lambda k: "".join("ACGT"[x] for x in rng.integers(0, 4, size=k))
+    with open(tmp_path / "messy.fa", "w") as f:
+        def rec(name, s):
+            f.write(f">{name} some description\n")
+            for a in range(0, len(s), 70):
+                f.write(s[a:a + 70] + "\n")
+        for q, gi in enumerate(order):
+            s = bytes(g.seqs[gi]).decode()
+            if q == 2:
+                rec("uncategorized_contig", acgt(5000))                   # not in the conversion table
+            if q == 4:
+                rec(g.names[order[0]], acgt(3000))                        # repeated id: ignored
+                rec("short_one", "ACGTNNNNNNNNNNNNNNNNNNacgtacgtacgtACG")   # 7 symbols after compaction: filtered
+            if q == 5:
+                s = s[:10000] + "N" * 50 + s[10000:20000].lower() + s[20000:]   # dropped characters inside a genome
+            rec(g.names[gi], s)
+    lines = open(tmp_path / "seqid.map").read().splitlines()
+    lines.insert(3, "absent_from_fasta_1\t%d" % g.taxids[0])
+    lines.append("short_one\t%d" % g.taxids[1])
+    lines.append("absent_from_fasta_2\t999999")                                 # tax id outside the tree
+    lines.append("%s\t%d" % (g.names[order[1]], g.taxids[(order[1] + 1) % len(g.names)]))   # second tax id for a listed name
+    open(tmp_path / "messy.map", "w").write("\n".join(lines) + "\n")
+    common = ["-r", str(tmp_path / "messy.fa"), "--taxonomy-tree", str(tmp_path / "nodes.dmp"), "--name-table", str(tmp_path / "names.dmp"),
+              "--conversion-table", str(tmp_path / "messy.map")] + (["--ignore-uncategorized-genome"] if ignore_uncategorized else [])
+    ref_prefix, own_prefix = str(tmp_path / "ref"), str(tmp_path / "own")
+    subprocess.run([os.path.join(REF_DIR, "centrifuger-build"), "-t", "4", "-o", ref_prefix] + common, check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger-build"), "-t", "4", "-o", own_prefix] + common, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    err = r.stderr.decode()
+    assert "taxonomy id doesn't exist for uncategorized_contig" in err and "short_one is filtered" in err
+    ref, mine = parse_1cfr(ref_prefix + ".1.cfr"), parse_1cfr(own_prefix + ".1.cfr")
+    assert len(mine) == len(ref)
+    for (na, va), (nb, vb) in zip(mine, ref):
+        assert na == nb and va == vb, f"field {na} differs"
+    for k in (2, 3):
+        assert open(f"{own_prefix}.{k}.cfr", "rb").read() == open(f"{ref_prefix}.{k}.cfr", "rb").read(), f".{k}.cfr differs"
+    # and the reference classifies identically on either index (reads from all genomes + the uncategorized contig)
+    reads = synth.make_reads(g, 400, 120, seed=3)
+    synth.write_fastq(reads, str(tmp_path / "r.fq"))
+    out = []
+    for pre in (ref_prefix, own_prefix):
+        out.append(subprocess.run([os.path.join(REF_DIR, "centrifuger"), "-x", pre, "-u", str(tmp_path / "r.fq"), "-t", "2"], check=True,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout)
+    assert out[0] == out[1]
+
+
+def test_build_entry_rejects_bad_genome_lists(tmp_path):
+    """cfr_build_index validates before it touches the text: empty text, a genome shorter than --ftabchars + 1, an id twice."""
+    g = synth.make_genomes(n_species=2, n_strains=1, genome_len=500, seed=3)
+    for kw, lens in ((dict(), [0, 0]), (dict(), [500, 5]), (dict(genome_seq=[0, 0]), [500, 500])):
+        text = np.concatenate([g.seqs[0][:lens[0]], g.seqs[1][:lens[1]]]) if sum(lens) else np.zeros(1, dtype=np.uint8)
+        with pytest.raises(capi.CfrError):
+            capi.build_index(g.names, g.taxids, (text, np.array(lens, dtype=np.uint64)), g.nodes, g.tax_names, str(tmp_path / "bad"), **kw)

@@ -64,12 +64,12 @@ def test_rank_and_access_exhaustive(iname, dev):
 
 @pytest.mark.parametrize("iname", VARIANTS)
 def test_derived_tables_are_consistent_with_the_bwt(iname, dev):
-    """SA / ISA / 2-bit text (list ranking by rulers) and the locate memo against the BWT itself, for every row: the head and
-    the tail of the LF list included (the rows before the first ruler once had no owner).  Runs in whatever form the process
-    is in (u32 entries, or 5-byte entries under CFR_FORCE_WIDE in tests/test_gpu_variants.py)."""
+    """SA / 2-bit text (list ranking by rulers) and the direct locate (memo, or suffix array + step function) against the BWT
+    itself, for every row: the head and the tail of the LF list included (the rows before the first ruler once had no owner).
+    Runs in whatever form the process is in (u32 entries, or 36-bit packed entries under CFR_FORCE_WIDE in tests/test_gpu_variants.py)."""
     c = dev(iname).selfcheck()
     assert (c["bad_sa_isa"], c["bad_text"], c["bad_lf"], c["bad_memo"]) == (0, 0, 0, 0), c
-    if not os.environ.get("CFR_TEXT_MODE") and not os.environ.get("CFR_PROFILE") and not os.environ.get("CFR_LAYOUT"):
+    if not os.environ.get("CFR_TEXT_MODE") and not os.environ.get("CFR_PROFILE") and not os.environ.get("CFR_LAYOUT") and not os.environ.get("CFR_STEPS_OFF"):
         assert c["text_tables"]
 
 

@@ -16,6 +16,20 @@ VARIANTS = {
     "no_derived_tables": {"CFR_FTABX_WIDTH": "0", "CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0"},
     "text_mode_early": {"CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "tiny_subbatches_sparse_memo": {"CFR_SUBBATCH": "37", "CFR_LOC_MEMO_GB": "0.0003", "CFR_TAPER_FLOOR": "0"},
+    # no suffix array: the sparse memo is what the locate walks stop at (multi-kernel locate path)
+    "sparse_memo_without_text_mode": {"CFR_TEXT_MODE": "0", "CFR_LOC_MEMO_GB": "0.0003", "CFR_SUBBATCH": "41"},
+    # the lean image of a 40 Gbp index forced on the small ones: 36-bit packed suffix array, 8-byte K-mer entries, no locate
+    # memo (every row is located through the suffix array and the step function)
+    "lean_image": {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_LOC_MEMO_GB": "0"},
+    "lean_image_text_mode_early": {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_FTABX_WIDTH": "8", "CFR_LOC_MEMO_GB": "0", "CFR_TEXT_MIN_L": "8"},
+    "no_memo_locate_by_steps": {"CFR_LOC_MEMO_GB": "0"},
+    "ftabx_8_byte_entries": {"CFR_FTABX_E8": "1", "CFR_FTABX_WIDTH": "12"},
+    # the sampled rows "do not follow" the step function: no text mode, locate memo by the plain walk
+    "step_function_rejected": {"CFR_STEPS_OFF": "1"},
+    # the pool behind the virtual rows of text-space hits with more than 4 rows: too small at first (grows), pinned too small
+    # (the sub-batch is repeated with hits in row space)
+    "virtual_row_pool_growth": {"CFR_VPOOL_INIT": "3", "CFR_WIDE_ROWS": "24", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
+    "virtual_row_pool_pinned": {"CFR_VPOOL_CAP": "3", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
     "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "post_pool_growth": {"CFR_POOL_INIT": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
@@ -26,7 +40,7 @@ VARIANTS = {
     "wide_ftabx_one_block_per_cu": {"CFR_FTABX_WIDTH": "12", "CFR_BLOCKS_PER_CU": "1"},
     # the reference's own compressed components in HBM (rank lines, wavelet trees, run-block rank): whole parity file
     "run_block_layout": {"CFR_LAYOUT": "rb"},
-    # the n >= 2^32 code path (5-byte SA / ISA entries, WIDE search kernel) forced on the small indexes
+    # the n >= 2^32 code path (36-bit packed SA entries, WIDE search kernel) forced on the small indexes
     "wide_tables": {"CFR_FORCE_WIDE": "1"},
     "wide_tables_text_mode_early": {"CFR_FORCE_WIDE": "1", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     # ranges of 5 .. 24 rows continue on the text ("wide text mode"): off, and cut down to 6 rows
@@ -57,6 +71,8 @@ def test_parity_suite_under_switches(name):
 
 
 @pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"}),
+                                        ("lean_image", {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_LOC_MEMO_GB": "0"}),
+                                        ("virtual_row_pool_growth", {"CFR_VPOOL_INIT": "7"}), ("virtual_row_pool_pinned", {"CFR_VPOOL_CAP": "7"}),
                                         ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"}),
                                         ("post_stage_overlapped", {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "20000"}),
                                         ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"})])
