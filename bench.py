@@ -246,7 +246,7 @@ def kernel_source_sha():
     return h.hexdigest()[:12]
 
 
-def live_pmc(args, cache):
+def live_pmc(args, cache, gpu=0):
     """HBM-side counters of k_search_chains_v2 measured in THIS run: the bench re-executes itself (--inner: warm-up + one
     2 M-read step, a single launch) under `rocprofv3 --pmc ... --kernel-trace` - one pass per counter group, as the guide
     prescribes - plus one un-profiled pass with the kernel's diagnostic instantiation for its iteration mix.
@@ -265,6 +265,10 @@ def live_pmc(args, cache):
              "--species", str(args.species), "--strains", str(args.strains), "--genome-len", str(args.genome_len), "--divergence-step", str(args.divergence_step),
              "--read-len", str(args.read_len), "--seed", str(args.seed), "--builder", args.builder, "--cache", args.cache] + (["--index-gbp", str(args.index_gbp)] if args.index_gbp else [])
     env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n_inner), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k_, None)           # the child is a plain one-process run on this rank's GPU
+    if gpu:
+        env["HIP_VISIBLE_DEVICES"] = str(gpu)
     vals, dur = {}, None
     work = tempfile.mkdtemp(prefix="cfr_pmc_", dir="/tmp")
     try:
@@ -452,7 +456,21 @@ def main():
     ap.add_argument("--workload", choices=["cfg2", "strains20"], default="cfg2",
                     help="cfg2 = the metric's index (50 species x 5 strains 1 %% apart); strains20 = the data-sensitivity case: "
                          "25 species x 20 strains 0.1 %% apart x 2 Mbp (ranges of ~20 rows per hit: wide text mode, team fold)")
+    ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default=None,
+                    help="BASELINE.json presets, per rank (so that --gpus 8 runs the configuration as written): cfg2 = configs[1] (default); "
+                         "cfg3 = configs[2] (10 M pairs, -k 5); cfg4 = configs[3]: 40 Gbp index, 12.5 M x 150 bp reads per rank per step (100 M over 8 ranks); "
+                         "cfg5 = configs[4]: 40 Gbp index, long reads 5-20 kbp, 2.5 M per rank over the timed steps (312 500 per step: the bases of one "
+                         "step are 3.9 GB beside a 245 GB image)")
+    ap.add_argument("--sdust-steps", type=int, default=5, help="timed steps of the legs with the SDUST pre-step on the device")
     args = ap.parse_args()
+    if args.config == "cfg3":
+        args.mode = "pe"
+    elif args.config == "cfg4":
+        args.index_gbp, args.reads = 40.0, 12_500_000
+    elif args.config == "cfg5":
+        args.index_gbp, args.mode, args.reads = 40.0, "long", 312_500
+        if args.steps == 3:
+            args.steps = 8          # 8 x 312 500 = cfg5's 2.5 M long reads per rank
     if args.workload == "strains20":
         args.species, args.strains, args.genome_len, args.divergence_step = 25, 20, 2_000_000, 0.001
     if args.index_gbp:
@@ -512,7 +530,7 @@ def main():
     cat_d = torch.from_numpy(np.ascontiguousarray(cat)).to(device)
     longmode = args.mode == "long"
     if longmode and args.reads == 10_000_000:
-        args.reads = 200_000 if args.index_gbp else 1_000_000
+        args.reads = 312_500 if args.index_gbp else 1_000_000
     if longmode and args.cpu_sample == 2_000_000:
         args.cpu_sample = 20_000
     if longmode and args.count_sample == 200_000:
@@ -592,9 +610,10 @@ def main():
     step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    step()
+    for _ in range(args.sdust_steps):
+        step()
     torch.cuda.synchronize()
-    ms_with_dust = 1000.0 * (time.perf_counter() - t1)
+    ms_with_dust = 1000.0 * (time.perf_counter() - t1) / args.sdust_steps
     dev.set_dust(False)
     # the other result layout, timed alike (sub-result)
     entry["compact"] = not entry["compact"]
@@ -641,7 +660,7 @@ def main():
                                   "note": "the same step through the other entry (rank 0's own clock): the results are the same fields in the other widths"}
     out["with_device_sdust"] = {"value": args.reads / (ms_with_dust / 1e3), "unit": out["unit"], "ms_per_step": ms_with_dust,
                                 "note": "the same step with the reference's default pre-step (SDUST, CentrifugerClass.cpp:276-316) done on the device: "
-                                        "unmasked reads resident in HBM in, private masked copy + k_dust + the step; one process, one step timed"}
+                                        f"unmasked reads resident in HBM in, private masked copy + k_dust + the step; rank 0's clock over {args.sdust_steps} steps", "steps": args.sdust_steps}
 
     # ---- roofline of the dominant kernel
     import oracle_lib as ora
@@ -677,8 +696,11 @@ def main():
               "per": "one step = the launches of the step's sub-batches (traffic and kernel_ms are summed over them)",
               "measured_copy_GBs": copy_gbs}
       if pmc is None and args.mode == "se" and args.read_len == 150:
-          try:    # no live passes: the committed profile of the same kernel, flagged as such
+          try:    # no live passes: the committed profile of the same kernel, flagged as such - and only when it was taken on this
+              # very index size with this very kernel source (another image has another request mix: traffic stays null then)
               pmj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
+              if abs(float(pmj.get("index_bp", 1e9)) - float(info.n)) > 0.02 * float(info.n) or pmj.get("kernel_source_sha") != kernel_source_sha():
+                  raise ValueError("committed profile is of another index size or kernel source")
               pm = pmj["k_search_chains_v2"]
               pmc = {"source": f"COMMITTED profile profiles/pmc_latest.json ({pmj.get('round')}), not this run", "reads": pmj["reads_in_profiled_launch"],
                      "rdreq": pm["TCC_EA0_RDREQ"], "rdreq_32b": pm.get("TCC_EA0_RDREQ_32B") or 0.0, "fetch_size_kib": pm["FETCH_SIZE_KiB"],
@@ -710,7 +732,7 @@ def main():
           if pmc.get("prof"):
               pr = pmc["prof"]
               useful = (16 * (pr.get("table", 0) + pr.get("table10", 0)) + 48 * pr.get("ext_two_records", 0) + 24 * (pr.get("ext", 0) - pr.get("ext_two_records", 0))
-                        + 16 * pr.get("text_rows", 0) + 16 * pr.get("sa", 0) + 8 * pr.get("isa", 0) + 16 * pr.get("block_loads", 0) + 32 * c.get("hits", 0) / ns)
+                        + 16 * pr.get("text_rows", 0) + 16 * pr.get("sa", 0) + 64 * pr.get("saw", 0) + 32 * pr.get("text_hits", 0) + 16 * pr.get("block_loads", 0) + 32 * c.get("hits", 0) / ns)
               roof["useful_bytes_per_read"] = useful
               roof["iteration_mix_per_read"] = pr
               roof["fetched_over_useful"] = (per_read_rd + per_read_wr) / useful if useful else None
@@ -728,10 +750,10 @@ def main():
     # ---- CPU baselines + parity
     cli_job = None
     refbin = os.path.join(ROOT, "oracle", "_ref", "centrifuger")
-    if not args.no_cpu_baseline and os.path.exists(refbin) and world == 1:    # reported baseline: rank 0 at N = 1 only
+    if not args.no_cpu_baseline and os.path.exists(refbin):    # reported baseline: rank 0 (the other ranks have left; at N > 1 on a smaller sample)
         from centrifuger_amd import synth
         ncpu = os.cpu_count() or 1
-        nb = min(args.cpu_sample, args.reads)
+        nb = min(args.cpu_sample if world == 1 else max(1, args.cpu_sample // 4), args.reads)
         rs = synth.ReadSet(*sample_of(reads_d, nb))
         fa = os.path.join(cache, f"sample_{rank}.fa")
         synth.write_fasta(rs, fa)
@@ -796,6 +818,16 @@ def main():
             out["pcie_inclusive"]["pinned_value"] = args.reads / (time.perf_counter() - t0)
             out["pcie_inclusive"]["pinned_note"] = f"{args.reads} reads, bases / offsets / results / matches all in cfr_host_alloc memory"
             out["pcie_inclusive"]["host_entry_equals_resident_entry"] = bool(res_keep.tobytes() == results[:nb].tobytes())
+            # what a host caller with the reference's default options gets: unmasked reads in pinned host memory, SDUST on the device
+            dev.set_dust(True)
+            dev.classify(pb.array, po.array, results=results, matches=matches)
+            t0 = time.perf_counter()
+            for _ in range(args.sdust_steps):
+                dev.classify(pb.array, po.array, results=results, matches=matches)
+            out["pcie_inclusive"]["pinned_with_sdust_value"] = args.reads * args.sdust_steps / (time.perf_counter() - t0)
+            out["pcie_inclusive"]["pinned_with_sdust_note"] = (f"cfr_classify_batch with cfr_device_index_set_dust(1): {args.reads} unmasked reads from cfr_host_alloc memory, "
+                                                               f"results to cfr_host_alloc memory, {args.sdust_steps} steps")
+            dev.set_dust(False)
             pb.free()
             po.free()
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
@@ -829,7 +861,7 @@ def main():
     dev.close()
     del reads_d, reads2_d
     torch.cuda.empty_cache()
-    out["roofline"] = build_roofline(live_pmc(args, cache) if (world == 1 and not args.no_pmc) else None)
+    out["roofline"] = build_roofline(live_pmc(args, cache, local_rank) if not args.no_pmc else None)    # (rank 0's GPU; the other ranks have left)
     if cli_job is not None:
         # ---- end-to-end wall clock of the drop-in command line on the same file (parse + dust + device + TSV, index load included);
         # runs with the GPU to itself, like a user's run

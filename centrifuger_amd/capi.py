@@ -131,7 +131,8 @@ class BuildInput(C.Structure):
     _fields_ = [("n_seqs", C.c_uint64), ("seq_names", C.POINTER(C.c_char_p)), ("seq_taxids", C.c_void_p), ("seq_lens", C.c_void_p),
                 ("text", C.c_void_p), ("n_nodes", C.c_uint64), ("node_taxid", C.c_void_p), ("node_parent", C.c_void_p),
                 ("node_rank", C.POINTER(C.c_char_p)), ("n_names", C.c_uint64), ("name_taxid", C.c_void_p), ("name_text", C.POINTER(C.c_char_p)),
-                ("n_genomes", C.c_uint64), ("genome_seq", C.c_void_p), ("genome_lens", C.c_void_p), ("n_extra", C.c_uint64)]
+                ("n_genomes", C.c_uint64), ("genome_seq", C.c_void_p), ("genome_lens", C.c_void_p), ("n_extra", C.c_uint64),
+                ("n_present_taxids", C.c_uint64), ("present_taxids", C.c_void_p)]
 
 
 class BuildOptions(C.Structure):

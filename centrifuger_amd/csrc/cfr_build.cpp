@@ -204,7 +204,9 @@ void write_taxonomy(const std::string &path, const BuildInput &in) {
     tree[nd.taxid] = {nd.parent, rk};
   }
   std::set<uint64_t> selected;                                   // the ids on the paths from the sequences' ids to the root
-  for (uint64_t tid : std::set<uint64_t>(in.taxids.begin(), in.taxids.end())) {
+  std::set<uint64_t> present(in.taxids.begin(), in.taxids.end());
+  present.insert(in.present_taxids.begin(), in.present_taxids.end());
+  for (uint64_t tid : present) {
     uint64_t p = tid;
     if (!tree.count(p)) continue;
     while (!selected.count(p)) {

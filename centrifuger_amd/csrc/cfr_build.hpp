@@ -35,6 +35,7 @@ struct TaxNode { uint64_t taxid, parent; std::string rank; };
 struct BuildInput {
   std::vector<std::string> names;          // sequence names, conversion-table order = sequence ids; the last n_extra are extra names (no tax id)
   std::vector<uint64_t> taxids;            // original tax id of every conversion-table sequence
+  std::vector<uint64_t> present_taxids;    // further ids the conversion table mentions (their lineages stay in the tree)
   uint64_t n_extra = 0;
   std::vector<uint64_t> genome_seq, lens;  // the genomes of the text, text order: sequence id and length (ACGT only)
   const uint8_t *text = nullptr;           // the genomes back to back, upper-case ACGT

@@ -151,7 +151,7 @@ int main(int argc, char *argv[]) {
   if (tree.empty() || names_dmp.empty() || conv.empty()) { print_log("Need to use --taxonomy-tree, --name-table and --conversion-table."); return EXIT_FAILURE; }
 
   // ---- taxonomy files (Taxonomy::Init, Taxonomy.hpp:146-180)
-  std::vector<uint64_t> node_taxid, node_parent, name_taxid, seq_taxid;
+  std::vector<uint64_t> node_taxid, node_parent, name_taxid, seq_taxid, present_taxid;
   std::vector<std::string> node_rank, name_text, seq_name;
   {
     std::vector<std::string> lines;
@@ -190,11 +190,12 @@ int main(int argc, char *argv[]) {
       return path;
     };
     std::map<std::string, size_t> first_at;
-    for (const std::string &ln : lines) {
+    for (const std::string &ln : lines) {   // (every tax id the table mentions keeps its lineage in the tree, Taxonomy.hpp:275-300)
       if (ln.empty() || ln[0] == '#') continue;
       char nm[4096];
       unsigned long long tid;
       if (sscanf(ln.c_str(), "%4095s %llu", nm, &tid) != 2) continue;
+      present_taxid.push_back(tid);
       auto it = first_at.find(nm);
       if (it == first_at.end()) {
         first_at.emplace(nm, seq_name.size());
@@ -292,6 +293,7 @@ int main(int argc, char *argv[]) {
   memset(&in, 0, sizeof(in));
   in.n_seqs = seq_name.size(); in.seq_names = p_seq.data(); in.seq_taxids = seq_taxid.data(); in.seq_lens = nullptr; in.text = text.data();
   in.n_genomes = genome_seq.size(); in.genome_seq = genome_seq.data(); in.genome_lens = genome_lens.data(); in.n_extra = n_extra;
+  in.n_present_taxids = present_taxid.size(); in.present_taxids = present_taxid.data();
   in.n_nodes = node_taxid.size(); in.node_taxid = node_taxid.data(); in.node_parent = node_parent.data(); in.node_rank = p_rank.data();
   in.n_names = name_taxid.size(); in.name_taxid = name_taxid.data(); in.name_text = p_names.data();
   cfr_build_report rep;

@@ -146,6 +146,7 @@ cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *o
       if (i < in->n_seqs - in->n_extra) bi.taxids.push_back(in->seq_taxids[i]);
     }
     bi.n_extra = in->n_extra;
+    if (in->n_present_taxids && in->present_taxids) bi.present_taxids.assign(in->present_taxids, in->present_taxids + in->n_present_taxids);
     if (in->n_genomes) {
       bi.genome_seq.assign(in->genome_seq, in->genome_seq + in->n_genomes);
       bi.lens.assign(in->genome_lens, in->genome_lens + in->n_genomes);

@@ -34,7 +34,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_VPOS, S_VPOS1, S_VCTL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -315,7 +315,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   view_.ftabx = nullptr;
   view_.ftabx_width = 0;
   view_.ftabx_e8 = 0;
-  view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0; view_.vpos = nullptr;
+  view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
   memset(&view_.steps, 0, sizeof(view_.steps));
   uint32_t log4n = 0;
   while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
@@ -653,7 +653,7 @@ DeviceIndex::Staged DeviceIndex::stage_inputs(const uint8_t *b1, const uint64_t 
 // size the dense arrays; everything else stays on the device.  Two halves: launch_search (caps, scan, the search kernel)
 // is also what the one-launch post stage of classify_device follows; launch_post is everything behind the search kernel.
 DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                                  uint64_t total1, uint64_t total2, int par, bool row_space_only, unsigned long long *vctl) {
+                                                  uint64_t total1, uint64_t total2, int par, bool row_space_only) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
   const size_t nchains = n * (size_t)cpr;
@@ -669,22 +669,11 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   uint32_t *chain_cnt = (uint32_t *)scratch(par ? S_CHAINCNT1 : S_CHAINCNT, nchains * 4);
   size_t tmp_bytes = scan_tmp_bytes(n);
   void *tmp = scratch(par ? S_SCAN1 : S_SCAN, tmp_bytes);
-  // text-space hits (k_search_chains_v2): four text positions per raw hit slot, and a pool behind them for hits of more rows
+  // text-space hits (k_search_chains_v2, virt_text_pos): searches that finish on the text keep virtual rows
   const bool text_hits = !search_v1_ && !row_space_only && have_sa() && view_.steps.pos && view_.text2;
-  uint64_t *vpos = nullptr;
-  if (text_hits) {
-    if (!vpool_cap_) {
-      vpool_cap_ = std::max<uint64_t>(cap_total, 1ull << 16);
-      if (const char *e = dbg_env("CFR_VPOOL_INIT")) vpool_cap_ = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // test hook: first size (grows on overflow)
-    }
-    if (const char *e = dbg_env("CFR_VPOOL_CAP")) vpool_cap_ = strtoull(e, nullptr, 10);                               // test hook: fixed size (no growth)
-    vpos = (uint64_t *)scratch(par ? S_VPOS1 : S_VPOS, (4 * cap_total + vpool_cap_ + 4) * 8);
-    if (!vctl) vctl = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8);
-  }
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
   HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
-  if (text_hits) HIP_CHECK(hipMemsetAsync(vctl, 0, 16, stream_));
   k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
   exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[1], stream_));
@@ -712,7 +701,6 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
     sv.sa = text_hits ? (wide_ ? view_.sa36 : view_.sa32) : nullptr;
     sv.ftabx_e8 = view_.ftabx_e8;
-    sv.vpos = vpos; sv.vpool_base = 4 * cap_total; sv.vpool_cap = vpool_cap_; sv.vctl = vctl;
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
@@ -740,7 +728,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
-  return SearchBuf{hit_off, raw, chain_cnt, cap_total, vpos};
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
 }
 
 // Translated search (Classifier::TranslatedSearch): 6 chains per mate (strand x frame), one lane each
@@ -765,7 +753,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   else k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
-  return SearchBuf{hit_off, raw, chain_cnt, cap_total, nullptr};
+  return SearchBuf{hit_off, raw, chain_cnt, cap_total};
 }
 
 void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
@@ -806,7 +794,7 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
     HIP_CHECK(hipEventRecord(ev_[4], st));
     HIP_CHECK(hipEventRecord(ev_[5], st));
     HIP_CHECK(hipEventRecord(ev_[6], st));
-    p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f, sb.vpos};
+    p = Pipe{hit_off, fin_cnt, read_row_off, nullptr, vals_f, fin, 0, nrows_f};
     last_stats.n_chains += nchains;
     last_stats.n_rows += nrows_f;
     return;
@@ -842,13 +830,13 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
     if (nhits) k_enum_rows<<<grid_for(nhits), kBlock, 0, st>>>(view_, nhits, hits, row_off, rows);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipEventRecord(ev_[5], st));
-    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, st>>>(view_with(sb.vpos), rows, nrows, vals, nullptr);
+    if (nrows) k_locate<<<grid_for(nrows), kBlock, 0, st>>>(view_, rows, nrows, vals, nullptr);
     HIP_CHECK(hipGetLastError());
   } else {
     HIP_CHECK(hipEventRecord(ev_[5], st));
   }
   HIP_CHECK(hipEventRecord(ev_[6], st));
-  p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows, sb.vpos};
+  p = Pipe{hit_off, fin_off, row_off, rows, vals, hits, nhits, nrows};
   last_stats.n_chains += nchains;
   last_stats.n_hits += nhits;
   last_stats.n_rows += nrows;
@@ -858,21 +846,7 @@ void DeviceIndex::launch_post(const SearchBuf &sb, const uint8_t *d_b1, const ui
 void DeviceIndex::run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                     uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
                                     bool fused, bool row_space_only) {
-  SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0, row_space_only);
-  if (sb.vpos) {
-    // the pool of virtual rows may run dry (many hits of more than 4 rows): this form has a host round trip anyway, so the
-    // flag is read here and the search repeated with a larger pool - and without text-space hits when that is not enough
-    unsigned long long *vctl = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8), h_ctl[2] = {0, 0};
-    for (int attempt = 0;; ++attempt) {
-      HIP_CHECK(hipMemcpyAsync(h_ctl, vctl, 16, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
-      if (!h_ctl[1]) break;
-      const bool give_up = attempt >= 3 || dbg_env("CFR_VPOOL_CAP");
-      if (!give_up) vpool_cap_ *= 4;
-      sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0, give_up);
-      if (give_up) break;
-    }
-  }
+  const SearchBuf sb = launch_search(d_b1, d_o1, d_b2, d_o2, n, total1, total2, 0, row_space_only);
   launch_post(sb, d_b1, d_o1, d_b2, d_o2, n, want_rows, p, hit_begin_host, fused, stream_);
 }
 
@@ -1003,11 +977,14 @@ void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const ui
 // Whole Query on the device.  matches: max_result > 0 -> read i owns [i*max_result, ...); otherwise the
 // read's slice of the located-row space.  *match_extent = number of match slots the caller must provide.
 // The batch is cut into sub-batches ("pieces"): the D2H copy of piece k (copy stream) overlaps the kernels of k+1.
-std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool per_read_slots, size_t &sb) const {
+std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool per_read_slots, size_t &sb, uint64_t total_bases) const {
   // full sub-batches, then the last one is halved down to taper_floor_ reads so that the copy left exposed after the
-  // last kernel is small; at most kMaxSub pieces (one event set each)
+  // last kernel is small; at most kMaxSub pieces (one event set each).  sub_batch_ is in reads of 150 bases: longer reads
+  // make shorter sub-batches (the buffers of a sub-batch are sized by its bases)
   const size_t kTaperMax = 4;
-  sb = per_read_slots ? std::max(sub_batch_, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;   // row-space matches: one piece
+  size_t want = sub_batch_;
+  if (n && total_bases / n > 300) want = std::max<size_t>(1, (size_t)((double)sub_batch_ * 150.0 / ((double)total_bases / (double)n)));
+  sb = per_read_slots ? std::max(want, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;   // row-space matches: one piece
   std::vector<std::pair<size_t, size_t>> pieces;
   size_t lo = 0;
   while (n - lo > sb) { pieces.emplace_back(lo, sb); lo += sb; }
@@ -1047,9 +1024,27 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   }
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/src == nullptr);
   size_t sb = 0;
-  const auto pieces = cut_pieces(n, stride > 0, sb);
+  const auto pieces = cut_pieces(n, stride > 0, sb, total1 + total2);
   const size_t nsub = pieces.size();
   const bool paired = d_b2 != nullptr;
+  // bases of every piece (its buffers are sized by them): from the caller's offsets, or 8 bytes per boundary from the device
+  std::vector<uint64_t> pt1(nsub, total1), pt2(nsub, total2);
+  if (nsub > 1) {
+    std::vector<uint64_t> b1(nsub + 1, 0), b2(nsub + 1, 0);
+    for (size_t k = 0; k <= nsub; ++k) {
+      const size_t at = k < nsub ? pieces[k].first : n;
+      if (src) { b1[k] = src->o1[at]; if (paired) b2[k] = src->o2[at]; }
+      else {
+        HIP_CHECK(hipMemcpyAsync(&b1[k], d_o1 + at, 8, hipMemcpyDeviceToHost, stream_));
+        if (paired) HIP_CHECK(hipMemcpyAsync(&b2[k], d_o2 + at, 8, hipMemcpyDeviceToHost, stream_));
+      }
+    }
+    if (!src) HIP_CHECK(hipStreamSynchronize(stream_));
+    // one size for all pieces (the largest): the scratch buffers are then allocated once, not regrown under running kernels
+    uint64_t m1 = 0, m2 = 0;
+    for (size_t k = 0; k < nsub; ++k) { m1 = std::max(m1, b1[k + 1] - b1[k]); if (paired) m2 = std::max(m2, b2[k + 1] - b2[k]); }
+    for (size_t k = 0; k < nsub; ++k) { pt1[k] = m1; pt2[k] = m2; }
+  }
   const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
@@ -1125,19 +1120,15 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   std::vector<size_t> todo;                 // pieces still to do
   for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
-    unsigned long long *pin = (unsigned long long *)pinned((2 + 4 * kMaxSub) * 8);    // one block: the pointers below stay valid
+    unsigned long long *pin = (unsigned long long *)pinned((2 + 2 * kMaxSub) * 8);    // one block: the pointers below stay valid
     uint32_t *ovf = (uint32_t *)pin + 4;  // behind the two u64 totals
     unsigned long long *heavy_h = pin + 2 + kMaxSub;   // reads k_tail_heavy folded, per sub-batch
     for (size_t k = 0; k < kMaxSub; ++k) heavy_h[k] = 0;
     if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
     const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
-    unsigned long long *vctl_d = (unsigned long long *)scratch(S_VCTL, 2 * kMaxSub * 8);
-    unsigned long long *vctl_h = pin + 2 + 2 * kMaxSub;   // {cursor, overflow} of the virtual-row pool, per sub-batch
     for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
       TailEntry *pool_e = (TailEntry *)scratch(S_POOL_E, pool_cap_ * sizeof(TailEntry));
       uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap_ * 8);
-      for (size_t k = 0; k < 2 * kMaxSub; ++k) vctl_h[k] = 0;
-      HIP_CHECK(hipMemsetAsync(vctl_d, 0, 2 * kMaxSub * 8, stream_));
       for (size_t k : todo) {
         const size_t lo = pieces[k].first, cnt = pieces[k].second;
         ovf[k] = 0;
@@ -1149,8 +1140,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const int par = tail_overlap ? (int)(k & 1) : 0;
         hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
         if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
-        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, par, false, vctl_d + 2 * k);
-        const DevView vv = view_with(sbuf.vpos);
+        const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], par);
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
         if (tail_overlap) {
           HIP_CHECK(hipEventRecord(search_done_[par], stream_));
@@ -1165,15 +1155,15 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
         // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
-        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(vv, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                       pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
-        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(vv, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
         if (heavy) {
           const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * (tail_overlap && tail_blocks_per_cu_ ? std::min(5, 2 * tail_blocks_per_cu_) : 5)));
-          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(vv, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
                                                                            (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(vv, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
+          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
                                                                     (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
         }
         HIP_CHECK(hipGetLastError());
@@ -1181,7 +1171,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
-      if (have_sa()) HIP_CHECK(hipMemcpyAsync(vctl_h, vctl_d, 2 * kMaxSub * 8, hipMemcpyDeviceToHost, stream_));   // (behind every search of this round)
       HIP_CHECK(hipStreamSynchronize(stream_));
       HIP_CHECK(hipStreamSynchronize(tail_stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
@@ -1192,17 +1181,10 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         heavy_frac_ = (double)hv / (double)n;
       }
       std::vector<size_t> again;
-      bool tail_dry = false, vrows_dry = false;
-      for (size_t k : todo) {
-        if (ovf[k]) tail_dry = true;                                      // the post stage's scratch pool ran dry in this sub-batch
-        if (vctl_h[2 * k + 1]) vrows_dry = true;                          // the search's pool of virtual rows did
-        if (ovf[k] || vctl_h[2 * k + 1]) again.push_back(k);
-      }
+      for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
       todo.swap(again);
-      if (todo.empty()) break;
-      if ((tail_dry && (pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP"))) || (vrows_dry && dbg_env("CFR_VPOOL_CAP"))) break;
-      if (tail_dry) pool_cap_ = std::min(pool_cap_ * 4, pool_limit);     // kept for the calls that follow: the workload needs it
-      if (vrows_dry) vpool_cap_ *= 4;
+      if (todo.empty() || pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP")) break;
+      pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it
     }
   }
   const bool repeated = one_launch && !todo.empty();
@@ -1212,8 +1194,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     ev_ = evs_[k];
     Pipe p;
-    run_device_stages(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, total1, total2, true, p, nullptr, fused);
-    const DevView vv = view_with(p.vpos);
+    run_device_stages(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], true, p, nullptr, fused);
     const uint64_t extent = stride ? stride * cnt : p.nrows;
     if (!stride) {
       if (match_extent) *match_extent = extent;
@@ -1223,9 +1204,9 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     cfr_result *d_res;
     cfr_match *d_match;
     out_buffers(k, extent, d_res, d_match, stream_);
-    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(vv, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
+    if (fused) k_tail<true><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.hit_off, p.fin_off, p.hits,
                                                                   p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
-    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(vv, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
+    else k_tail<false><<<grid_for(cnt), kBlock, 0, stream_>>>(view_, cnt, d_o1 + lo, paired ? d_o2 + lo : nullptr, p.fin_off, nullptr, p.hits,
                                                               p.row_off, p.vals, entries, d_res, d_match, stride, stride * lo);
     HIP_CHECK(hipGetLastError());
     copy_out(k, d_res, d_match, extent, nullptr, nullptr, stream_);

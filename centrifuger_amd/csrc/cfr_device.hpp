@@ -17,11 +17,11 @@
 //              SA[row] (u32 entries for n < 2^32, 36-bit packed entries up to 2^36) and the 2-bit text.  A BWT range of a few rows
 //              is then extended by comparing the read with the text 48 bases per step (the rows' suffix positions move in
 //              lock step), instead of one LF step per base.  A hit found that way is kept in TEXT-POSITION space: its rows
-//              are "virtual rows" (kVirtRow | index into the sub-batch's vpos array, which holds the text position of
-//              every row of the hit), so no inverse suffix array exists anywhere.
+//              are "virtual rows" (the range the search had when it moved to the text, which of its rows survived, and how
+//              many characters were matched since: virt_text_pos), so no inverse suffix array exists anywhere.
 //   steps    : DERIVED at load time: what FMIndex::BackwardToSampledSA returns, as a step function of the TEXT POSITION of
 //              the row it starts from (breakpoints: position 0 and the selectedSA positions; the premise is verified on
-//              every sampled row, k_memo_check).  locate(row) = steps(SA[row]); locate(virtual row) = steps(vpos[..]).
+//              every sampled row, k_memo_check).  locate(row) = steps(SA[row]); locate(virtual row) = steps(SA[entry row] - matched).
 //   loc_memo : DERIVED at load time when HBM allows: the value FMIndex::BackwardToSampledSA returns for every memo_rate-th row
 //              (memo_rate = 1 when n*4 bytes fit the budget).  The LF-walk from row i passes through the same rows
 //              as the reference's, so stopping at a memoised row returns exactly what the full walk would.
@@ -66,7 +66,7 @@ struct ProtView {
   char list[32];             // code -> character
 };
 
-// rows >= kVirtRow are virtual: row & ~kVirtRow indexes the sub-batch's vpos array (text position of that row of a hit)
+// rows >= kVirtRow are virtual: rows of a hit that was finished on the text (layout: virt_text_pos in cfr_kernels.hip.inc)
 constexpr uint64_t kVirtRow = 1ull << 63;
 
 // BackwardToSampledSA as a step function of the text position (see cfr_kernels.hip.inc, steps_value)
@@ -94,7 +94,6 @@ struct DevView {            // passed by value to kernels
   const uint32_t *sa32;
   const uint32_t *sa36;     // entry i at bits [36 i, 36 i + 36) of the little-endian bit string
   StepView steps;           // locate as a function of the text position
-  const uint64_t *vpos;     // per launch: text positions behind the virtual rows of this sub-batch's hits
   const uint64_t *text2;    // symbol p at bits 2(p%32) of word p/32
   uint32_t text_min_l;      // a search switches to text comparison once it has matched this many characters
   const uint64_t *sel_rows, *sel_vals;
@@ -184,15 +183,14 @@ class DeviceIndex {
   struct Staged { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; uint64_t t1, t2; };
   Staged stage_inputs(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n);
   // device stages shared by run_batch / classify_device; returns (nhits, nrows) and leaves device pointers in p_
-  struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; const uint64_t *vpos; };
+  struct Pipe { uint64_t *hit_off, *fin_off, *row_off, *rows, *vals; cfr_hit *hits; uint64_t nhits, nrows; };
   void run_device_stages(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                          uint64_t total1, uint64_t total2, bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host,
                          bool fused = false, bool row_space_only = false);
-  struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; uint64_t *vpos; };
-  // row_space_only: no text mode (every hit carries real BWT rows); vctl: {pool cursor, overflow flag} of the virtual-row pool
+  struct SearchBuf { uint64_t *hit_off; cfr_hit *raw; uint32_t *chain_cnt; uint64_t cap_total; };
+  // row_space_only: no text mode (every hit carries real BWT rows)
   SearchBuf launch_search(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                          uint64_t total1, uint64_t total2, int par = 0, bool row_space_only = false, unsigned long long *vctl = nullptr);
-  DevView view_with(const uint64_t *vpos) const { DevView v = view_; v.vpos = vpos; return v; }
+                          uint64_t total1, uint64_t total2, int par = 0, bool row_space_only = false);
   bool have_sa() const { return view_.sa32 != nullptr || view_.sa36 != nullptr; }
   // every row (real or virtual) of a hit can be located by one table access: memo at every row, or SA + step function
   bool locate_direct() const { return (view_.loc_memo && view_.memo_shift == 0) || (have_sa() && view_.steps.pos); }
@@ -200,7 +198,7 @@ class DeviceIndex {
                                   uint64_t total1, uint64_t total2);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                    bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
-  std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb) const;
+  std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb, uint64_t total_bases = 0) const;
   void dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_t n, hipStream_t st);
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
@@ -231,7 +229,6 @@ class DeviceIndex {
   uint64_t nblk1_ = 0, nblk2_ = 0;
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false, team_tail_ = true;
   bool wide_ = false;                  // n >= 2^32: 36-bit SA entries and the WIDE search kernel
-  uint64_t vpool_cap_ = 0;             // entries of the virtual-row pool behind the inline part of vpos (hits of more than 4 rows)
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;

@@ -260,6 +260,10 @@ typedef struct {
   const uint64_t *genome_seq;       /* sequence id (index into seq_names) of every genome of the text, in text order; no id twice */
   const uint64_t *genome_lens;      /* their lengths; seq_lens is not read when n_genomes > 0 */
   uint64_t n_extra;                 /* the LAST n_extra entries of seq_names are extra names (Taxonomy::AddExtraSeqName): seq_taxids not read for them */
+  /* further tax ids whose lineages stay in the tree: Taxonomy::Init keeps every id the conversion table MENTIONS
+   * (Taxonomy.hpp:275-300), also one that no sequence ends up with (a name listed twice gets the LCA of its ids) */
+  uint64_t n_present_taxids;
+  const uint64_t *present_taxids;
 } cfr_build_input;
 typedef struct {
   int32_t ftab_chars;   /* --ftabchars, default 10 */

@@ -26,10 +26,6 @@ VARIANTS = {
     "ftabx_8_byte_entries": {"CFR_FTABX_E8": "1", "CFR_FTABX_WIDTH": "12"},
     # the sampled rows "do not follow" the step function: no text mode, locate memo by the plain walk
     "step_function_rejected": {"CFR_STEPS_OFF": "1"},
-    # the pool behind the virtual rows of text-space hits with more than 4 rows: too small at first (grows), pinned too small
-    # (the sub-batch is repeated with hits in row space)
-    "virtual_row_pool_growth": {"CFR_VPOOL_INIT": "3", "CFR_WIDE_ROWS": "24", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
-    "virtual_row_pool_pinned": {"CFR_VPOOL_CAP": "3", "CFR_TEXT_MIN_L": "8", "CFR_FTABX_WIDTH": "0"},
     "two_kernel_post_stage": {"CFR_FUSED_POST": "0"},
     "post_pool_overflow_redo": {"CFR_POOL_CAP": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
     "post_pool_growth": {"CFR_POOL_INIT": "3", "CFR_SUBBATCH": "50", "CFR_TAPER_FLOOR": "0"},
@@ -72,7 +68,6 @@ def test_parity_suite_under_switches(name):
 
 @pytest.mark.parametrize("name,extra", [("wide_tables", {"CFR_FORCE_WIDE": "1"}), ("no_wide_text_mode", {"CFR_WIDE_ROWS": "0"}),
                                         ("lean_image", {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_LOC_MEMO_GB": "0"}),
-                                        ("virtual_row_pool_growth", {"CFR_VPOOL_INIT": "7"}), ("virtual_row_pool_pinned", {"CFR_VPOOL_CAP": "7"}),
                                         ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"}),
                                         ("post_stage_overlapped", {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "20000"}),
                                         ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"})])
