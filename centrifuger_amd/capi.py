@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcfr_hip.so")
 
-CFR_OK, CFR_ERR_IO, CFR_ERR_FORMAT, CFR_ERR_NO_DEVICE, CFR_ERR_HIP, CFR_ERR_ARG, CFR_ERR_CAPACITY = range(7)
+CFR_OK, CFR_ERR_IO, CFR_ERR_FORMAT, CFR_ERR_NO_DEVICE, CFR_ERR_HIP, CFR_ERR_ARG, CFR_ERR_CAPACITY, CFR_ERR_BUSY = range(8)
 
 
 class CfrError(RuntimeError):
@@ -76,6 +76,7 @@ EXPORTS = [
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
+    "cfr_classify_batch_submit", "cfr_classify_batch_wait",
 ]
 
 _lib = None
@@ -361,6 +362,25 @@ class DeviceIndex:
                 continue
             _check(st)
             return results, matches[:nm.value]
+
+    def submit(self, bases1, offsets1, bases2=None, offsets2=None, results=None, matches=None):
+        """cfr_classify_batch_submit: queue a batch, return a ticket object for wait().  The arrays are kept alive by the ticket."""
+        bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
+        n = len(offsets1) - 1
+        if results is None:
+            results = np.zeros(n, dtype=RESULT_DTYPE)
+        if matches is None:
+            matches = np.zeros(max(16, max(1, self.index.params.max_result) * n), dtype=MATCH_DTYPE)
+        t = C.c_uint64(0)
+        _check(lib().cfr_classify_batch_submit(self._d, _p(bases1), _p(offsets1), _p(bases2), _p(offsets2), C.c_size_t(n),
+                                               _p(results), _p(matches), C.c_size_t(len(matches)), C.byref(t)))
+        return {"ticket": t.value, "keep": (bases1, offsets1, bases2, offsets2), "results": results, "matches": matches}
+
+    def wait(self, job):
+        """cfr_classify_batch_wait: the (results, matches) of a submitted batch"""
+        nm = C.c_size_t(0)
+        _check(lib().cfr_classify_batch_wait(self._d, C.c_uint64(job["ticket"]), C.byref(nm)))
+        return job["results"], job["matches"][:nm.value]
 
     def classify_resident(self, d_bases1: int, d_offsets1: int, n: int, total1: int, d_bases2: int = 0, d_offsets2: int = 0,
                           total2: int = 0, results=None, matches=None):

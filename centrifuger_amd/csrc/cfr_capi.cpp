@@ -1,6 +1,12 @@
 // cfr_capi.cpp — the extern "C" surface declared in include/cfr_hip.h.
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 
@@ -9,7 +15,24 @@
 #include "cfr_tail.hpp"
 
 struct cfr_index { cfr::HostIndex *h; };
-struct cfr_dev_index { cfr::DeviceIndex *d; const cfr_index *host; int tail_threads; };
+// One call at a time per device image: `busy` is held for the length of every entry that touches the image (try_lock:
+// CFR_ERR_BUSY for the second caller) and by the worker thread while it runs a submitted batch.
+struct cfr_async_job { std::function<cfr_status(std::string &, size_t &)> run; uint64_t ticket; };
+struct cfr_async_done { cfr_status status; std::string err; size_t n_matches; };
+struct cfr_dev_index {
+  cfr::DeviceIndex *d; const cfr_index *host; int tail_threads;
+  std::mutex busy;
+  // submitted batches (cfr_classify_batch_submit / _wait)
+  std::mutex qmu;
+  std::condition_variable qcv, dcv;
+  std::deque<cfr_async_job> queue;
+  std::map<uint64_t, cfr_async_done> done;
+  std::set<uint64_t> live;                               // tickets handed out and not yet waited for
+  uint64_t next_ticket = 1;
+  bool stop = false, worker_started = false;
+  std::thread worker;
+  cfr_dev_index(cfr::DeviceIndex *dd, const cfr_index *h, int t) : d(dd), host(h), tail_threads(t) {}
+};
 
 namespace {
 thread_local std::string g_err;
@@ -30,6 +53,39 @@ template <class F> cfr_status guarded(F &&f) {
   }
 }
 cfr_status bad_arg(const char *m) { g_err = m; return CFR_ERR_ARG; }
+
+// entry guard: the image's buffers, streams and statistics belong to one call at a time
+struct BusyGuard {
+  std::unique_lock<std::mutex> lk;
+  explicit BusyGuard(cfr_dev_index *d) : lk(d->busy, std::try_to_lock) {}
+  bool ok() const { return lk.owns_lock(); }
+};
+#define CFR_ENTER(d, what)                                                                                                   \
+  BusyGuard busy_guard_(d);                                                                                                  \
+  if (!busy_guard_.ok()) { g_err = what ": this cfr_dev_index is in use by another call (one call at a time per device image)"; return CFR_ERR_BUSY; }
+
+void worker_loop(cfr_dev_index *d) {
+  for (;;) {
+    cfr_async_job job;
+    {
+      std::unique_lock<std::mutex> lk(d->qmu);
+      d->qcv.wait(lk, [&] { return d->stop || !d->queue.empty(); });
+      if (d->queue.empty()) return;                      // stop, nothing left to run
+      job = std::move(d->queue.front());
+      d->queue.pop_front();
+    }
+    cfr_async_done r{CFR_OK, "", 0};
+    {
+      std::lock_guard<std::mutex> run(d->busy);          // (waits for a synchronous call that is inside the image)
+      r.status = job.run(r.err, r.n_matches);
+    }
+    {
+      std::lock_guard<std::mutex> lk(d->qmu);
+      d->done.emplace(job.ticket, std::move(r));
+    }
+    d->dcv.notify_all();
+  }
+}
 
 void fill_info(const cfr::HostIndex &h, cfr_index_info *info, uint64_t dev_bytes) {
   memset(info, 0, sizeof(*info));
@@ -95,14 +151,24 @@ cfr_status cfr_device_index_create_ex(const cfr_index *idx, int device, const cf
   if (o.ftabx_width < -1 || o.ftabx_width > 16) return bad_arg("cfr_device_index_create_ex: ftabx_width out of range");
   return guarded([&]() -> cfr_status {
     cfr::DeviceIndex *d = new cfr::DeviceIndex(*idx->h, device, o);
-    *out = new cfr_dev_index{d, idx, default_tail_threads()};
+    *out = new cfr_dev_index(d, idx, default_tail_threads());
     return CFR_OK;
   });
 }
 cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out) {
   return cfr_device_index_create_ex(idx, device, nullptr, out);
 }
-void cfr_device_index_destroy(cfr_dev_index *d) { if (d) { delete d->d; delete d; } }
+void cfr_device_index_destroy(cfr_dev_index *d) {
+  if (!d) return;
+  if (d->worker_started) {                               // queued batches run to completion first (their buffers are the caller's)
+    { std::lock_guard<std::mutex> lk(d->qmu); d->stop = true; }
+    d->qcv.notify_all();
+    d->worker.join();
+  }
+  { std::lock_guard<std::mutex> wait_for_a_running_call(d->busy); }
+  delete d->d;
+  delete d;
+}
 cfr_status cfr_device_index_get_info(const cfr_dev_index *d, cfr_index_info *info) {
   if (!d || !info) return bad_arg("cfr_device_index_get_info: null argument");
   fill_info(d->d->host(), info, d->d->device_bytes());
@@ -113,17 +179,20 @@ cfr_status cfr_rank_batch(cfr_dev_index *d, const char *chars, const uint64_t *p
                           uint64_t *out_rank, char *out_access) {
   if (!d || (n && (!chars || !pos || !inclusive))) return bad_arg("cfr_rank_batch: null argument");
   for (size_t i = 0; i < n; ++i) if (pos[i] >= d->d->host().n) return bad_arg("cfr_rank_batch: position out of range");
+  CFR_ENTER(d, "cfr_rank_batch");
   return guarded([&]() -> cfr_status { d->d->rank_batch(chars, pos, inclusive, n, out_rank, out_access); return CFR_OK; });
 }
 cfr_status cfr_backward_search_batch(cfr_dev_index *d, const uint8_t *bases, const uint64_t *offsets, const uint32_t *m, size_t n,
                                      uint64_t *out_l, uint64_t *out_sp, uint64_t *out_ep) {
   if (!d || (n && (!bases || !offsets || !m || !out_l || !out_sp || !out_ep))) return bad_arg("cfr_backward_search_batch: null argument");
   for (size_t i = 0; i < n; ++i) if (m[i] > offsets[i + 1] - offsets[i]) return bad_arg("cfr_backward_search_batch: m exceeds read length");
+  CFR_ENTER(d, "cfr_backward_search_batch");
   return guarded([&]() -> cfr_status { d->d->backward_search_batch(bases, offsets, m, n, out_l, out_sp, out_ep); return CFR_OK; });
 }
 cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps) {
   if (!d || (n && (!rows || !out_val))) return bad_arg("cfr_locate_rows: null argument");
   for (size_t i = 0; i < n; ++i) if (rows[i] >= d->d->host().n) return bad_arg("cfr_locate_rows: row out of range");
+  CFR_ENTER(d, "cfr_locate_rows");
   return guarded([&]() -> cfr_status { d->d->locate_rows(rows, n, out_val, out_steps); return CFR_OK; });
 }
 
@@ -170,6 +239,7 @@ cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *o
 
 cfr_status cfr_selfcheck_tables(cfr_dev_index *d, uint64_t out[6]) {
   if (!d || !out) return bad_arg("cfr_selfcheck_tables: null argument");
+  CFR_ENTER(d, "cfr_selfcheck_tables");
   return guarded([&]() -> cfr_status { d->d->selfcheck(out); return CFR_OK; });
 }
 
@@ -177,6 +247,7 @@ cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint6
                             const uint64_t *offsets2, size_t n, cfr_hit *out_hits, size_t hit_cap, uint64_t *hit_begin) {
   if (!d || !hit_begin || (n && (!bases1 || !offsets1))) return bad_arg("cfr_search_batch: null argument");
   if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_search_batch: bases2/offsets2 must both be given");
+  CFR_ENTER(d, "cfr_search_batch");
   return guarded([&]() -> cfr_status {
     cfr::DeviceIndex::BatchOut out;
     d->d->run_batch_host(bases1, offsets1, bases2, offsets2, n, false, out);
@@ -192,10 +263,49 @@ cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uin
                               size_t *n_matches) {
   if (!d || (n && (!bases1 || !offsets1 || !results))) return bad_arg("cfr_classify_batch: null argument");
   if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch: bases2/offsets2 must both be given");
+  CFR_ENTER(d, "cfr_classify_batch");
   return guarded([&]() -> cfr_status {
     d->d->classify_host(bases1, offsets1, bases2, offsets2, n, results, matches, match_cap, n_matches);
     return CFR_OK;
   });
+}
+
+cfr_status cfr_classify_batch_submit(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
+                                     const uint64_t *offsets2, size_t n, cfr_result *results, cfr_match *matches, size_t match_cap,
+                                     cfr_ticket *ticket) {
+  if (!d || !ticket || (n && (!bases1 || !offsets1 || !results))) return bad_arg("cfr_classify_batch_submit: null argument");
+  if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch_submit: bases2/offsets2 must both be given");
+  std::lock_guard<std::mutex> lk(d->qmu);
+  if (d->live.size() >= CFR_MAX_PENDING) { g_err = "cfr_classify_batch_submit: CFR_MAX_PENDING batches are outstanding on this cfr_dev_index"; return CFR_ERR_BUSY; }
+  if (!d->worker_started) { d->worker = std::thread(worker_loop, d); d->worker_started = true; }
+  cfr_async_job job;
+  job.ticket = d->next_ticket++;
+  job.run = [=](std::string &err, size_t &nm) -> cfr_status {
+    const cfr_status st = guarded([&]() -> cfr_status {
+      d->d->classify_host(bases1, offsets1, bases2, offsets2, n, results, matches, match_cap, &nm);
+      return CFR_OK;
+    });
+    if (st != CFR_OK) err = g_err;                       // (the worker's thread-local message travels with the ticket)
+    return st;
+  };
+  *ticket = job.ticket;
+  d->live.insert(job.ticket);
+  d->queue.push_back(std::move(job));
+  d->qcv.notify_one();
+  return CFR_OK;
+}
+cfr_status cfr_classify_batch_wait(cfr_dev_index *d, cfr_ticket ticket, size_t *n_matches) {
+  if (!d) return bad_arg("cfr_classify_batch_wait: null argument");
+  std::unique_lock<std::mutex> lk(d->qmu);
+  if (!d->live.count(ticket)) { g_err = "cfr_classify_batch_wait: unknown ticket, or one that has been waited for already"; return CFR_ERR_ARG; }
+  d->live.erase(ticket);                                 // (a second waiter for the same ticket gets the error above)
+  d->dcv.wait(lk, [&] { return d->done.count(ticket) != 0; });
+  cfr_async_done r = std::move(d->done[ticket]);
+  d->done.erase(ticket);
+  lk.unlock();
+  if (n_matches) *n_matches = r.n_matches;
+  if (r.status != CFR_OK) g_err = r.err;
+  return r.status;
 }
 
 cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, const void *d_offsets1, const void *d_bases2,
@@ -203,6 +313,7 @@ cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, c
                                        cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches) {
   if (!d || (n && (!d_bases1 || !d_offsets1 || !results))) return bad_arg("cfr_classify_batch_resident: null argument");
   if ((d_bases2 == nullptr) != (d_offsets2 == nullptr)) return bad_arg("cfr_classify_batch_resident: mate buffers must both be given");
+  CFR_ENTER(d, "cfr_classify_batch_resident");
   return guarded([&]() -> cfr_status {
     d->d->classify_device((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
                           (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, results, matches, match_cap, n_matches);
@@ -215,6 +326,7 @@ cfr_status cfr_classify_batch_resident_compact(cfr_dev_index *d, const void *d_b
                                                cfr_result_compact *results, cfr_match_compact *matches, size_t match_cap, size_t *n_matches) {
   if (!d || (n && (!d_bases1 || !d_offsets1 || !results || !matches))) return bad_arg("cfr_classify_batch_resident_compact: null argument");
   if ((d_bases2 == nullptr) != (d_offsets2 == nullptr)) return bad_arg("cfr_classify_batch_resident_compact: mate buffers must both be given");
+  CFR_ENTER(d, "cfr_classify_batch_resident_compact");
   return guarded([&]() -> cfr_status {
     d->d->classify_device((const uint8_t *)d_bases1, (const uint64_t *)d_offsets1, (const uint8_t *)d_bases2,
                           (const uint64_t *)d_offsets2, n, total_bases1, total_bases2, reinterpret_cast<cfr_result *>(results),
@@ -278,11 +390,13 @@ cfr_status cfr_dust_mask_batch_literal(uint8_t *bases, const uint64_t *offsets, 
 
 cfr_status cfr_device_index_set_dust(cfr_dev_index *d, int on) {
   if (!d) return bad_arg("cfr_device_index_set_dust: null argument");
+  CFR_ENTER(d, "cfr_device_index_set_dust");
   d->d->set_dust(on != 0);
   return CFR_OK;
 }
 cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n) {
   if (!d || (n && (!bases || !offsets))) return bad_arg("cfr_dust_mask_device: null argument");
+  CFR_ENTER(d, "cfr_dust_mask_device");
   return guarded([&]() -> cfr_status {
     d->d->dust_mask_host(bases, offsets, n);
     return CFR_OK;

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <type_traits>
 
 #include "cfr_tail.hpp"      // dust_mask: the host twin the device SDUST falls back to
@@ -178,22 +179,43 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     auto lines_of = [&](const RawBitvector &bv) -> RankLines {
       const uint64_t nl = bv.n / 448 + 2;
       std::vector<uint64_t> L(nl * 8, 0);
-      uint64_t ones = 0;
-      for (uint64_t k = 0; k < nl; ++k) {
-        L[k * 8] = ones;
-        for (int wq = 0; wq < 7; ++wq) {
-          // payload word wq of line k = bits [448k + 64wq, +64) of the vector (unaligned gather from the 64-bit words)
-          const uint64_t bit = k * 448 + (uint64_t)wq * 64;
-          uint64_t w = 0;
-          if (bit < bv.n) {
-            const uint64_t wi = bit >> 6, sh = bit & 63;
-            w = bv.bits[wi] >> sh;
-            if (sh && wi + 1 < bv.bits.size()) w |= bv.bits[wi + 1] << (64 - sh);
-            if (bit + 64 > bv.n) w &= (1ull << (bv.n - bit)) - 1;      // nothing beyond the last bit
+      // payload word wq of line k = bits [448k + 64wq, +64) of the vector (unaligned gather from the 64-bit words); the line's
+      // first word = ones before the line.  Parts of the vector are laid out by host threads (12 GB of bitvectors at 40 Gbp),
+      // each with counts relative to its own start; the parts' totals are added afterwards.
+      const unsigned parts = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, nl >> 16), std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
+      std::vector<uint64_t> part_ones(parts + 1, 0);
+      auto fill = [&](unsigned t) {
+        const uint64_t lo = nl * t / parts, hi = nl * (t + 1) / parts;
+        uint64_t ones = 0;
+        for (uint64_t k = lo; k < hi; ++k) {
+          L[k * 8] = ones;
+          for (int wq = 0; wq < 7; ++wq) {
+            const uint64_t bit = k * 448 + (uint64_t)wq * 64;
+            uint64_t w = 0;
+            if (bit < bv.n) {
+              const uint64_t wi = bit >> 6, sh = bit & 63;
+              w = bv.bits[wi] >> sh;
+              if (sh && wi + 1 < bv.bits.size()) w |= bv.bits[wi + 1] << (64 - sh);
+              if (bit + 64 > bv.n) w &= (1ull << (bv.n - bit)) - 1;      // nothing beyond the last bit
+            }
+            L[k * 8 + 1 + wq] = w;
+            ones += (uint64_t)__builtin_popcountll(w);
           }
-          L[k * 8 + 1 + wq] = w;
-          ones += (uint64_t)__builtin_popcountll(w);
         }
+        part_ones[t + 1] = ones;
+      };
+      if (parts == 1) fill(0);
+      else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < parts; ++t) th.emplace_back(fill, t);
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < parts; ++t) part_ones[t + 1] += part_ones[t];
+        th.clear();
+        for (unsigned t = 1; t < parts; ++t) th.emplace_back([&, t]() {
+          const uint64_t lo = nl * t / parts, hi = nl * (t + 1) / parts, base = part_ones[t];
+          for (uint64_t k = lo; k < hi; ++k) L[k * 8] += base;
+        });
+        for (auto &x : th) x.join();
       }
       uint64_t *d = (uint64_t *)temp_alloc(L.size() * 8);
       rb_allocs.push_back(d);
@@ -503,6 +525,14 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
   }
   lap("locate memo");
+  {
+    // what a sub-batch's buffers may take: 40 % of the HBM still free now that the image stands, at most 32 GB (cut_pieces)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const double budget = std::min(32e9, 0.4 * (double)free_b);
+      piece_bases_max_ = (uint64_t)std::max(2.5e8, budget / 2.7);
+    }
+  }
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
 }
@@ -979,11 +1009,14 @@ void DeviceIndex::run_batch_host(const uint8_t *b1, const uint64_t *o1, const ui
 // The batch is cut into sub-batches ("pieces"): the D2H copy of piece k (copy stream) overlaps the kernels of k+1.
 std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool per_read_slots, size_t &sb, uint64_t total_bases) const {
   // full sub-batches, then the last one is halved down to taper_floor_ reads so that the copy left exposed after the
-  // last kernel is small; at most kMaxSub pieces (one event set each).  sub_batch_ is in reads of 150 bases: longer reads
-  // make shorter sub-batches (the buffers of a sub-batch are sized by its bases)
+  // last kernel is small; at most kMaxSub pieces (one event set each).  A sub-batch of long reads is as large as the HBM left
+  // beside the image allows (its raw hit lists take ~2.7 bytes per base): the search kernel walks one chain per lane, and a
+  // launch with fewer chains than lanes runs at the pace of its longest reads (1 M long reads: 8.5e6 reads/s in one piece,
+  // 5.7e6 in twelve)
   const size_t kTaperMax = 4;
   size_t want = sub_batch_;
-  if (n && total_bases / n > 300) want = std::max<size_t>(1, (size_t)((double)sub_batch_ * 150.0 / ((double)total_bases / (double)n)));
+  if (n && total_bases && (double)want * ((double)total_bases / (double)n) > (double)piece_bases_max_)
+    want = std::max<size_t>(1, (size_t)((double)piece_bases_max_ / ((double)total_bases / (double)n)));
   sb = per_read_slots ? std::max(want, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;   // row-space matches: one piece
   std::vector<std::pair<size_t, size_t>> pieces;
   size_t lo = 0;

@@ -47,7 +47,8 @@ enum {
   CFR_ERR_NO_DEVICE = 3,   /* no HIP device / HIP runtime error at setup */
   CFR_ERR_HIP = 4,         /* HIP runtime error during a batch */
   CFR_ERR_ARG = 5,         /* bad argument */
-  CFR_ERR_CAPACITY = 6     /* caller-provided output buffer too small */
+  CFR_ERR_CAPACITY = 6,    /* caller-provided output buffer too small */
+  CFR_ERR_BUSY = 7         /* another thread is inside a call on this cfr_dev_index (or too many batches are queued) */
 };
 
 typedef struct cfr_index cfr_index;           /* host copy of <prefix>.{1,2,4}.cfr */
@@ -173,6 +174,25 @@ cfr_status cfr_search_batch(cfr_dev_index *d, const uint8_t *bases1, const uint6
 cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
                               const uint8_t *bases2, const uint64_t *offsets2, size_t n,
                               cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
+
+/* Asynchronous form of cfr_classify_batch.  The reference overlaps reading, classification and output of consecutive batches
+ * (CentrifugerClass.cpp:776-800: the next batch is read while the threads classify this one); a caller of this library gets the
+ * same by submitting batch k+1 before it waits for batch k:
+ *   cfr_classify_batch_submit  queues the call and returns at once with a ticket.  Every buffer handed over (reads, offsets,
+ *                              results, matches) must stay valid and untouched until the ticket has been waited for.
+ *   cfr_classify_batch_wait    blocks until that batch is done, returns ITS status (cfr_last_error() then holds its message)
+ *                              and, through n_matches, what cfr_classify_batch would have stored there.  A ticket is waited
+ *                              for exactly once.
+ * Batches of one cfr_dev_index run in submission order on the index's own worker thread; at most CFR_MAX_PENDING may be
+ * outstanding (CFR_ERR_BUSY beyond that).  cfr_device_index_destroy waits for queued batches first.
+ * One cfr_dev_index serves one call at a time: a synchronous entry (classify / search / probes / dust) called while another
+ * thread - or a queued batch - is inside the same cfr_dev_index returns CFR_ERR_BUSY instead of racing on its buffers. */
+#define CFR_MAX_PENDING 8
+typedef uint64_t cfr_ticket;
+cfr_status cfr_classify_batch_submit(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
+                                     const uint8_t *bases2, const uint64_t *offsets2, size_t n,
+                                     cfr_result *results, cfr_match *matches, size_t match_cap, cfr_ticket *ticket);
+cfr_status cfr_classify_batch_wait(cfr_dev_index *d, cfr_ticket ticket, size_t *n_matches);
 
 /* Same, with the read buffers ALREADY RESIDENT in this device's HBM (device pointers; the caller has
  * synchronised whatever produced them).  This is the entry bench.py times. */

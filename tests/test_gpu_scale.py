@@ -372,3 +372,50 @@ def test_very_long_read_among_short_ones(world):
         assert res[25]["query_length"] == len(big) and res[25]["n_match"] > 0
         orc.close()
         dev.close()
+
+
+def test_submitted_batches_equal_the_blocking_call_and_one_call_at_a_time(world):
+    """cfr_classify_batch_submit / _wait (the reference overlaps input, classification and output of consecutive batches,
+    CentrifugerClass.cpp:776-800): two batches submitted back to back give what the blocking entry gives, a ticket is waited for
+    once, and a synchronous entry that arrives while a queued batch is inside the device image gets CFR_ERR_BUSY."""
+    import time
+    k = 2
+    rs = world["reads"]
+    idx, dev = _open(world["prefix"], k)
+    half = N_READS // 2
+    oa = rs.offsets[:half + 1]
+    ob = rs.offsets[half:] - rs.offsets[half]
+    ba, bb = rs.bases[:int(oa[-1])], rs.bases[int(oa[-1]):]
+    want_a, want_b = dev.classify(ba, oa), dev.classify(bb, ob.astype(np.uint64))
+    ja = dev.submit(ba, oa)
+    jb = dev.submit(bb, ob.astype(np.uint64))
+    # the image is busy while the worker runs the batches: a synchronous probe must be refused, not raced
+    saw_busy = False
+    t0 = time.time()
+    while time.time() - t0 < 5.0 and not saw_busy:
+        try:
+            dev.locate(np.zeros(1, dtype=np.uint64))
+        except capi.CfrError as e:
+            assert e.status == capi.CFR_ERR_BUSY, e
+            saw_busy = True
+    got_b, got_a = dev.wait(jb), dev.wait(ja)            # (any order)
+    assert saw_busy
+    assert digest(*canon(*got_a, k)) == digest(*canon(*want_a, k))
+    assert digest(*canon(*got_b, k)) == digest(*canon(*want_b, k))
+    with pytest.raises(capi.CfrError) as ei:
+        dev.wait(ja)                                     # a ticket is waited for exactly once
+    assert ei.value.status == capi.CFR_ERR_ARG
+    # more than CFR_MAX_PENDING outstanding batches are refused
+    small_o = rs.offsets[:50001]
+    small_b = rs.bases[:int(small_o[-1])]
+    jobs = []
+    with pytest.raises(capi.CfrError) as ei:
+        for _ in range(64):
+            jobs.append(dev.submit(small_b, small_o))
+    assert ei.value.status == capi.CFR_ERR_BUSY and len(jobs) >= 8
+    ref_small = None
+    for j in jobs:
+        r = dev.wait(j)
+        ref_small = ref_small or digest(*canon(*r, k))
+        assert digest(*canon(*r, k)) == ref_small
+    dev.close()
