@@ -471,6 +471,10 @@ def main():
         args.index_gbp, args.mode, args.reads = 40.0, "long", 312_500
         if args.steps == 3:
             args.steps = 8          # 8 x 312 500 = cfg5's 2.5 M long reads per rank
+    if args.index_gbp >= 4 and args.cpu_sample == 2_000_000:
+        args.cpu_sample = 400_000       # the reference loads a 40 Gbp index for minutes per run: a smaller sample, no thread sweep
+    if args.config in ("cfg4", "cfg5"):
+        args.no_extra_configs = True
     if args.workload == "strains20":
         args.species, args.strains, args.genome_len, args.divergence_step = 25, 20, 2_000_000, 0.001
     if args.index_gbp:
@@ -778,13 +782,13 @@ def main():
         # its best thread count is not necessarily all cores
         nq = max(1, nb // 4)
         sweep = {}
-        if not paired:
+        if not paired and info.n < 4_000_000_000:      # (every run of the reference loads the index again: no sweep on large ones)
             fq = os.path.join(cache, f"sample_{rank}_q.fa")
             synth.write_fasta(rs.slice(0, nq), fq)
             for t in sorted({32, 64, 128, ncpu}):
                 if t <= ncpu:
                     sweep[t] = nq / max(ref_run(t, ["-u", fq])[0] - t_load, 1e-9)
-        best_t = max(sweep, key=sweep.get) if sweep else ncpu
+        best_t = max(sweep, key=sweep.get) if sweep else min(ncpu, 64)
         t_full, ref_tsv = ref_run(best_t, files)
         cpu_rate = nb / max(t_full - t_load, 1e-9)
         t_nodust, ref_tsv_nodust = ref_run(best_t, files, ["--no-dust"])
