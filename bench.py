@@ -423,6 +423,135 @@ def extra_config(torch, capi, ora, args, mode, prefix, cache, device):
     return out
 
 
+AA_LIST = "ARNDCEQGHILKMFPSTWYV"
+AA_CODON = {"A": "GCT", "R": "CGT", "N": "AAT", "D": "GAT", "C": "TGT", "E": "GAA", "Q": "CAA", "G": "GGT", "H": "CAT", "I": "ATT",
+            "L": "CTT", "K": "AAA", "M": "ATG", "F": "TTT", "P": "CCT", "S": "TCT", "T": "ACT", "W": "TGG", "Y": "TAT", "V": "GTT"}
+
+
+def protein_mode(torch, capi, args, device):
+    """translated search of 150 bp DNA reads against a protein index (FMIndex<Sequence_RunBlockOneTree>,
+    Classifier::TranslatedSearch, Classifier.hpp:463-506).  The index is written by the REFERENCE's `centrifuger-build --protein`
+    (oracle/_ref) from a synthetic proteome: --prot-species species x 5 strains (2 % substitutions per strain step) x 400 proteins of
+    ~300 aa.  Reads: 50-codon windows of random proteins, one codon per amino acid, 1 % substitutions, either strand.  One JSON line:
+    reads/s of cfr_classify_batch_resident (inputs resident in HBM), TSV parity and CPU baseline = the reference binary on a sample."""
+    from centrifuger_amd import synth
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    cache = os.path.join(args.cache, f"prot-{args.prot_species}-{args.seed}")
+    prefix = os.path.join(cache, "idx")
+    rng = np.random.default_rng(args.seed)
+    n_sp, n_st, n_pr = args.prot_species, 5, 400
+    os.makedirs(cache, exist_ok=True)
+    if not os.path.exists(prefix + ".done"):
+        t0 = time.time()
+        lens = rng.integers(150, 450, size=(n_sp, n_pr))
+        nodes, names = [(1, 1, "no rank")], [(1, "root")]
+        with open(os.path.join(cache, "prot.fa"), "wb") as fa, open(os.path.join(cache, "seqid.map"), "w") as mp:
+            aa = np.frombuffer(AA_LIST.encode(), dtype=np.uint8)
+            starts, total = [], 0
+            flat = []
+            for sp in range(n_sp):
+                sp_tid = 1000 + sp * 10
+                nodes.append((sp_tid, 1, "species")); names.append((sp_tid, f"species {sp}"))
+                base = [aa[rng.integers(0, 20, size=int(l))] for l in lens[sp]]
+                for k in range(n_st):
+                    st_tid = sp_tid + 1 + k
+                    nodes.append((st_tid, sp_tid, "strain")); names.append((st_tid, f"species {sp} strain {k}"))
+                    for pi, b in enumerate(base):
+                        q = b.copy()
+                        nm = int(len(q) * 0.02 * k)
+                        if nm:
+                            q[rng.integers(0, len(q), size=nm)] = aa[rng.integers(0, 20, size=nm)]
+                        name = f"P{sp}_{k}_{pi}"
+                        fa.write(b">" + name.encode() + b"\n" + q.tobytes() + b"\n")
+                        mp.write(f"{name}\t{st_tid}\n")
+                        flat.append(q); starts.append(total); total += len(q)
+        np.save(os.path.join(cache, "prot_cat.npy"), np.concatenate(flat))
+        np.save(os.path.join(cache, "prot_starts.npy"), np.array(starts + [total], dtype=np.int64))
+        with open(os.path.join(cache, "nodes.dmp"), "w") as f:
+            for t, par, rank in nodes:
+                f.write(f"{t}\t|\t{par}\t|\t{rank}\t|\n")
+        with open(os.path.join(cache, "names.dmp"), "w") as f:
+            for t, nm in names:
+                f.write(f"{t}\t|\t{nm}\t|\t\t|\tscientific name\t|\n")
+        log(f"proteome: {total/1e6:.1f} M amino acids in {len(starts)} proteins, {time.time()-t0:.1f}s")
+        t0 = time.time()
+        subprocess.run([os.path.join(ref_dir, "centrifuger-build"), "--protein", "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "prot.fa"),
+                        "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
+                        "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        log(f"protein index built by the reference's centrifuger-build --protein in {time.time()-t0:.1f}s")
+        open(prefix + ".done", "w").close()
+    cat = np.load(os.path.join(cache, "prot_cat.npy"))
+    starts = np.load(os.path.join(cache, "prot_starts.npy"))
+    plen = np.diff(starts)
+    n = args.reads if args.reads != 10_000_000 else 4_000_000
+    codon = np.zeros((256, 3), dtype=np.uint8)
+    for a, c in AA_CODON.items():
+        codon[ord(a)] = np.frombuffer(c.encode(), dtype=np.uint8)
+    pi = rng.integers(0, len(plen), size=n)
+    off = (rng.random(n) * (plen[pi] - 50)).astype(np.int64)
+    aa_win = cat[(starts[pi] + off)[:, None] + np.arange(50)[None, :]]
+    reads = codon[aa_win].reshape(n, 150)
+    mut = rng.random((n, 150)) < 0.01
+    reads[mut] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(mut.sum()))]
+    rc = rng.random(n) < 0.5
+    reads[rc] = synth.revcomp(reads[rc])
+    reads = np.ascontiguousarray(reads.reshape(-1))
+    offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(150)
+    reads_d = torch.from_numpy(reads).to(device)
+    offs_d = torch.from_numpy(offs.astype(np.int64)).to(device)
+    k = args.k if args.k is not None else 1
+    t0 = time.time()
+    idx = capi.Index(prefix, capi.default_params(max_result=k))
+    dev = capi.DeviceIndex(idx, device.index or 0)
+    info = dev.info()
+    log(f"protein index n={info.n} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
+    res_pin = capi.PinnedArray(n, capi.RESULT_DTYPE)
+    mat_pin = capi.PinnedArray(n * k, capi.MATCH_DTYPE)
+
+    def step():
+        return dev.classify_resident(reads_d.data_ptr(), offs_d.data_ptr(), n, n * 150, results=res_pin.array, matches=mat_pin.array)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kst = []
+    for _ in range(args.steps):
+        step()
+        kst.append(dev.last_stats())
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    results, matches = res_pin.array, mat_pin.array
+    out = {"metric": "classified reads/sec (150 bp, translated search against a protein index)", "value": n * args.steps / el, "unit": "reads/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u64", "data": "synthetic",
+           "config": {"workload": f"{info.n/1e6:.0f} M-symbol protein index ({n_sp} species x {n_st} strains x {n_pr} proteins, written by the reference's "
+                                  f"centrifuger-build --protein), {n} x 150 bp DNA reads per step, -k {k}, inputs resident in HBM", "index_symbols": int(info.n)},
+           "classified_fraction": float((results["n_match"] > 0).mean()),
+           "stage_ms": {kk: float(np.mean([getattr(s_, kk) for s_ in kst])) for kk in ("search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")}}
+    refbin = os.path.join(ref_dir, "centrifuger")
+    if not args.no_cpu_baseline and os.path.exists(refbin):
+        nb = min(args.cpu_sample if args.cpu_sample != 2_000_000 else 400_000, n)
+        rs = synth.ReadSet(reads[:nb * 150].copy(), offs[:nb + 1].copy())
+        fa = os.path.join(cache, "sample.fa")
+        synth.write_fasta(rs, fa)
+        one = os.path.join(cache, "one.fa")
+        synth.write_fasta(rs.slice(0, 1), one)
+        ncpu = os.cpu_count() or 1
+
+        def ref_run(t, f):
+            t0 = time.time()
+            o_ = subprocess.run([refbin, "-x", prefix, "-t", str(t), "-k", str(k), "-u", f], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            return time.time() - t0, o_
+        t_load = ref_run(min(ncpu, 64), one)[0]
+        t_full, ref_tsv = ref_run(min(ncpu, 64), fa)
+        own = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", results[i], matches) for i in range(nb))
+        out["cpu_baseline"] = {"value": nb / max(t_full - t_load, 1e-9), "unit": "reads/s", "cores": min(ncpu, 64), "kind": "reference",
+                               "sample": f"first {nb} reads, oracle/_ref/centrifuger -t {min(ncpu, 64)} -k {k} on the same protein index, wall {t_full:.1f}s minus index-load run {t_load:.1f}s"}
+        out["parity"] = {"reads": nb, "tsv_identical_to_reference": own == ref_tsv, "md5": hashlib.md5(own).hexdigest()}
+    print(json.dumps(out), flush=True)
+    dev.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,7 +575,8 @@ def main():
     ap.add_argument("--index-gbp", type=float, default=0.0, help="size of the synthetic index in Gbp (sets --species; same 5-strain model); "
                                                                   "0 = BASELINE configs[1] (1 Gbp, the metric's config)")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
-    ap.add_argument("--mode", choices=["se", "pe", "long"], default="se",
+    ap.add_argument("--prot-species", type=int, default=200, help="--mode protein: species of the synthetic proteome (x 5 strains x 400 proteins x ~300 aa)")
+    ap.add_argument("--mode", choices=["se", "pe", "long", "protein"], default="se",
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
                          "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")
     ap.add_argument("-k", type=int, default=None, help="max_result (default 1 for se, 5 for pe)")
@@ -516,6 +646,11 @@ def main():
     all_cpus = os.sched_getaffinity(0)
     numa = bind_to_gpu_numa_node(torch, local_rank)      # host threads + pinned buffers next to this rank's GPU
     from centrifuger_amd import capi
+    if args.mode == "protein":
+        if world != 1:
+            raise SystemExit("bench.py --mode protein is a one-GPU leg")
+        os.sched_setaffinity(0, all_cpus)
+        return protein_mode(torch, capi, args, device)
     key = cache_key(args)
     cache = os.path.join(args.cache, key)
     if rank == 0:
