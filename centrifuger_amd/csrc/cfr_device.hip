@@ -737,24 +737,38 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.wide_rows = kWideRows;
     if (const char *e = dbg_env("CFR_WIDE_ROWS")) sv.wide_rows = std::min<uint32_t>(kWideRows, (uint32_t)atoi(e));
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
-    if (dbg_env("CFR_SEARCH_PROF") && !paired && !wide) {
+    // few chains per lane (long reads): chains are handed out dynamically (DYN), one atomic per chain
+    bool dyn = nchains < 8ull * blocks * kBlock && (total1 + total2) / std::max<size_t>(1, nchains) >= 500;    // (per chain: half the mean read)
+    if (const char *e = dbg_env("CFR_SEARCH_DYN")) dyn = atoi(e) != 0;
+    unsigned long long *d_ctr = nullptr;
+    if (dyn) {
+      d_ctr = (unsigned long long *)scratch(S_P5, 16 * 8) + 15;
+      HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, stream_));
+    }
+    const uint64_t *p2 = paired ? packed2_ : nullptr, *o2 = paired ? d_o2 : nullptr;
+    const uint64_t nb2 = paired ? nblk2_ : 0;
+#define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
+    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr)
+    if (dbg_env("CFR_SEARCH_PROF") && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
-      HIP_CHECK(hipMemsetAsync(d_prof, 0, 16 * 8, stream_));
-      k_search_chains_v2<2, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt, d_prof);
-      HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 16 * 8, hipMemcpyDeviceToHost, stream_));
+      HIP_CHECK(hipMemsetAsync(d_prof, 0, 15 * 8, stream_));
+      if (wide) { if (dyn) CFR_LAUNCH_SEARCH(2, true, true, true, d_prof); else CFR_LAUNCH_SEARCH(2, true, true, false, d_prof); }
+      else { if (dyn) CFR_LAUNCH_SEARCH(2, true, false, true, d_prof); else CFR_LAUNCH_SEARCH(2, true, false, false, d_prof); }
+      HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 15 * 8, hipMemcpyDeviceToHost, stream_));
       HIP_CHECK(hipStreamSynchronize(stream_));
       static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "text_hits", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
-    } else
-    if (wide) {
-      if (paired) k_search_chains_v2<4, false, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
-      else k_search_chains_v2<2, false, true><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
-    } else
-    if (paired) k_search_chains_v2<4><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, packed2_, d_o2, n, nblk1_, nblk2_, hit_off, raw, chain_cnt);
-    else k_search_chains_v2<2><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, nullptr, nullptr, n, nblk1_, 0, hit_off, raw, chain_cnt);
+    } else if (wide) {
+      if (paired) { if (dyn) CFR_LAUNCH_SEARCH(4, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(4, false, true, false, nullptr); }
+      else { if (dyn) CFR_LAUNCH_SEARCH(2, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(2, false, true, false, nullptr); }
+    } else {
+      if (paired) { if (dyn) CFR_LAUNCH_SEARCH(4, false, false, true, nullptr); else CFR_LAUNCH_SEARCH(4, false, false, false, nullptr); }
+      else { if (dyn) CFR_LAUNCH_SEARCH(2, false, false, true, nullptr); else CFR_LAUNCH_SEARCH(2, false, false, false, nullptr); }
+    }
+#undef CFR_LAUNCH_SEARCH
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
