@@ -51,11 +51,13 @@ MATCH_COMPACT_DTYPE = np.dtype([("id_kind", "<u4"), ("taxid_lo", "<u4"), ("taxid
 COMPACT_WIDE = 1
 
 
-def expand_compact(cres, cmatch, max_result):
+def expand_compact(cres, cmatch, max_result, wide=None):
     """cfr_result_compact / cfr_match_compact arrays -> the wide arrays (RESULT_DTYPE, MATCH_DTYPE) with match_begin = i * max_result.
-    Raises if a read is flagged CFR_COMPACT_WIDE (its values did not fit: use the wide entry for such a batch)."""
-    if (cres["flags"] & COMPACT_WIDE).any():
-        raise ValueError("a read of the batch does not fit the compact result layout (CFR_COMPACT_WIDE)")
+    wide: DeviceIndex.compact_wide() of the same call - the reads flagged CFR_COMPACT_WIDE (values that do not fit the narrow
+    layout) are patched in from it; without it a flagged read raises."""
+    flagged = (cres["flags"] & COMPACT_WIDE) != 0
+    if flagged.any() and wide is None:
+        raise ValueError("a read of the batch does not fit the compact result layout (CFR_COMPACT_WIDE): pass DeviceIndex.compact_wide()")
     n = len(cres)
     res = np.zeros(n, dtype=RESULT_DTYPE)
     for f in ("score", "secondary_score", "hit_length", "query_length", "n_match"):
@@ -65,6 +67,18 @@ def expand_compact(cres, cmatch, max_result):
     mat["id"] = cmatch["id_kind"] & np.uint32(0x7fffffff)
     mat["kind"] = (cmatch["id_kind"] >> np.uint32(31)).astype(np.int32)
     mat["taxid"] = cmatch["taxid_lo"].astype(np.uint64) | (cmatch["taxid_hi"].astype(np.uint64) << np.uint64(32))
+    if flagged.any():
+        widx, wres, wmat = wide
+        assert set(np.nonzero(flagged)[0].tolist()) <= set(int(x) for x in widx), "flagged reads missing from the wide side list"
+        for j, i in enumerate(widx):
+            i = int(i)
+            if i >= n:
+                continue
+            mb = res["match_begin"][i]
+            res[i] = wres[j]
+            res["match_begin"][i] = mb
+            src = int(wres[j]["match_begin"])
+            mat[int(mb):int(mb) + max_result] = wmat[src:src + max_result]
     return res, mat
 
 EXPORTS = [
@@ -76,7 +90,7 @@ EXPORTS = [
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
-    "cfr_classify_batch_submit", "cfr_classify_batch_wait",
+    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads",
 ]
 
 _lib = None
@@ -362,6 +376,19 @@ class DeviceIndex:
                 continue
             _check(st)
             return results, matches[:nm.value]
+
+    def compact_wide(self):
+        """cfr_compact_wide_reads: (read_index, results, matches) of the reads the last compact call flagged CFR_COMPACT_WIDE"""
+        n = C.c_size_t(0)
+        pi, pr, pm = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().cfr_compact_wide_reads(self._d, C.byref(n), C.byref(pi), C.byref(pr), C.byref(pm)))
+        k = max(1, self.index.params.max_result)
+        if n.value == 0:
+            return np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=RESULT_DTYPE), np.zeros(0, dtype=MATCH_DTYPE)
+        idx = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+        res = np.frombuffer(C.string_at(pr, n.value * RESULT_DTYPE.itemsize), dtype=RESULT_DTYPE).copy()
+        mat = np.frombuffer(C.string_at(pm, n.value * k * MATCH_DTYPE.itemsize), dtype=MATCH_DTYPE).copy()
+        return idx, res, mat
 
     def submit(self, bases1, offsets1, bases2=None, offsets2=None, results=None, matches=None):
         """cfr_classify_batch_submit: queue a batch, return a ticket object for wait().  The arrays are kept alive by the ticket."""

@@ -335,6 +335,18 @@ cfr_status cfr_classify_batch_resident_compact(cfr_dev_index *d, const void *d_b
   });
 }
 
+cfr_status cfr_compact_wide_reads(cfr_dev_index *d, size_t *n, const uint32_t **read_index, const cfr_result **results, const cfr_match **matches) {
+  if (!d || !n) return bad_arg("cfr_compact_wide_reads: null argument");
+  CFR_ENTER(d, "cfr_compact_wide_reads");
+  const cfr::DeviceIndex &D = *d->d;
+  *n = (size_t)D.wide_total_;
+  if (read_index) *read_index = D.wide_idx_.data();
+  if (results) *results = D.wide_res_.data();
+  if (matches) *matches = D.wide_match_.data();
+  if (D.wide_total_ > D.wide_idx_.size()) { g_err = "cfr_compact_wide_reads: more flagged reads than the side list holds"; return CFR_ERR_CAPACITY; }
+  return CFR_OK;
+}
+
 void *cfr_host_alloc(size_t bytes) { return cfr::host_alloc_pinned(bytes); }
 void cfr_host_free(void *p) { cfr::host_free_pinned(p); }
 

@@ -35,7 +35,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -1131,6 +1131,18 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   if (src && !one_launch) throw HipError{"streamed host inputs need the one-launch post stage", -4};
   bring_piece(0);
 
+  // compact layout: the reads that do not fit it are also kept in the wide one (cfr_compact_wide_reads)
+  WideSide wide_side{nullptr, nullptr, nullptr, nullptr, 0};
+  wide_idx_.clear(); wide_res_.clear(); wide_match_.clear(); wide_total_ = 0;
+  if (compact) {
+    wide_side.cap = kWideSideCap;
+    wide_side.idx = (uint32_t *)scratch(S_WIDEIDX, kWideSideCap * 4);
+    wide_side.res = (cfr_result *)scratch(S_WIDERES, kWideSideCap * sizeof(cfr_result));
+    wide_side.match = (cfr_match *)scratch(S_WIDEMATCH, kWideSideCap * stride * sizeof(cfr_match));
+    wide_side.cnt = (unsigned long long *)scratch(S_WIDECNT, 8);
+    HIP_CHECK(hipMemsetAsync(wide_side.cnt, 0, 8, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));              // (the compaction kernels may run on another stream)
+  }
   // results / matches of piece k leave through the buffer pair of its parity while piece k+1 computes
   auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag, hipStream_t st,
                       const void *d_heavy = nullptr, unsigned long long *h_heavy = nullptr) {
@@ -1139,7 +1151,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     if (compact) {                          // the narrow layout is made on the device; what is copied out are its arrays
       cfr_result_compact *c_res = (cfr_result_compact *)scratch(par ? S_CRES1 : S_CRES, std::max(cnt, sb) * sizeof(cfr_result_compact));
       cfr_match_compact *c_match = (cfr_match_compact *)scratch(par ? S_CMATCH1 : S_CMATCH, (stride * std::max(cnt, sb) + 1) * sizeof(cfr_match_compact));
-      k_compact_results<<<grid_for(cnt), kBlock, 0, st>>>(d_res, d_match, cnt, stride, c_res, c_match);
+      k_compact_results<<<grid_for(cnt), kBlock, 0, st>>>(d_res, d_match, cnt, stride, c_res, c_match, (uint64_t)lo, wide_side);
       HIP_CHECK(hipGetLastError());
       d_res = reinterpret_cast<const cfr_result *>(c_res);
       d_match = reinterpret_cast<const cfr_match *>(c_match);
@@ -1261,6 +1273,18 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
   if (!one_launch) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
+  if (compact) {                            // the wide form of the flagged reads (a handful, if any)
+    unsigned long long cntw = 0;
+    HIP_CHECK(hipMemcpy(&cntw, wide_side.cnt, 8, hipMemcpyDeviceToHost));
+    wide_total_ = cntw;
+    const size_t take = (size_t)std::min<unsigned long long>(cntw, kWideSideCap);
+    if (take) {
+      wide_idx_.resize(take); wide_res_.resize(take); wide_match_.resize(take * stride);
+      HIP_CHECK(hipMemcpy(wide_idx_.data(), wide_side.idx, take * 4, hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(wide_res_.data(), wide_side.res, take * sizeof(cfr_result), hipMemcpyDeviceToHost));
+      HIP_CHECK(hipMemcpy(wide_match_.data(), wide_side.match, take * stride * sizeof(cfr_match), hipMemcpyDeviceToHost));
+    }
+  }
   if (!repeated) {                          // wall time of the device work: first event of the first piece to the last of the last
     float t = 0;
     (void)hipEventElapsedTime(&t, evs_[0][0], evs_[nsub - 1][7]);

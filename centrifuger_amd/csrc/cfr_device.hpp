@@ -166,6 +166,12 @@ class DeviceIndex {
                       size_t n, bool want_rows, BatchOut &out);
 
   cfr_batch_stats last_stats{};
+  // reads of the last compact call whose values did not fit the narrow layout, in the wide one (cfr_compact_wide_reads)
+  static constexpr size_t kWideSideCap = 65536;
+  std::vector<uint32_t> wide_idx_;
+  std::vector<cfr_result> wide_res_;
+  std::vector<cfr_match> wide_match_;
+  uint64_t wide_total_ = 0;
 
   // SDUST before the search of every classify call (off by default: the C-ABI contract is "already masked if the caller wants dust")
   void set_dust(bool on) { dust_ = on; }

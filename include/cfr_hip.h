@@ -48,7 +48,7 @@ enum {
   CFR_ERR_HIP = 4,         /* HIP runtime error during a batch */
   CFR_ERR_ARG = 5,         /* bad argument */
   CFR_ERR_CAPACITY = 6,    /* caller-provided output buffer too small */
-  CFR_ERR_BUSY = 7         /* another thread is inside a call on this cfr_dev_index (or too many batches are queued) */
+  CFR_ERR_BUSY = 7         /* another thread is inside a call on this device index, or too many batches are queued */
 };
 
 typedef struct cfr_index cfr_index;           /* host copy of <prefix>.{1,2,4}.cfr */
@@ -205,8 +205,9 @@ cfr_status cfr_classify_batch_resident(cfr_dev_index *d, const void *d_bases1, c
  * hundred million reads per second the step is co-limited by the device-to-host copy of its results (64 bytes per single-end
  * read, 160 per pair with -k 5); the fields are the same, in the widths they need for reads below 64 k bases.
  *   max_result > 0 only; the match slots of read i are [i * max_result, i * max_result + n_match) (no match_begin field).
+ *   The match slots a read does not use are zero.
  *   A read one of whose values does not fit (score >= 2^32, sequence id >= 2^31 ...) has CFR_COMPACT_WIDE set in `flags`: its
- *   other fields are not meaningful, cfr_classify_batch_resident gives them. */
+ *   other fields are not meaningful; cfr_compact_wide_reads hands out such reads in the wide layout (no second pass over the batch). */
 #define CFR_COMPACT_WIDE 1u
 typedef struct {
   uint32_t score, secondary_score;
@@ -222,6 +223,11 @@ cfr_status cfr_classify_batch_resident_compact(cfr_dev_index *d, const void *d_b
                                                const void *d_bases2, const void *d_offsets2, size_t n,
                                                uint64_t total_bases1, uint64_t total_bases2,
                                                cfr_result_compact *results, cfr_match_compact *matches, size_t match_cap, size_t *n_matches);
+/* The reads of the LAST cfr_classify_batch_resident_compact call on d that carry CFR_COMPACT_WIDE, in the wide layout: *n of them,
+ * read_index[j] = which read of the batch, results[j] = its cfr_result with match_begin pointing into matches[] (max_result slots
+ * per entry).  The arrays belong to d and stay valid until its next classify call.  CFR_ERR_CAPACITY (and *n = their number)
+ * if the batch held more than 65536 such reads: take cfr_classify_batch_resident for it. */
+cfr_status cfr_compact_wide_reads(cfr_dev_index *d, size_t *n, const uint32_t **read_index, const cfr_result **results, const cfr_match **matches);
 
 /* pinned host memory for result buffers (hipHostMalloc); NULL on failure */
 void *cfr_host_alloc(size_t bytes);

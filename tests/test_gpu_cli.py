@@ -111,3 +111,27 @@ def test_cli_option_corners_against_the_live_reference(name, profile, golden_dir
         got = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-t", "2"] + reads + opts + (["--gpu-throughput"] if profile == "throughput" else []),
                              check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
         assert got == want, (name, profile, reads[0])
+
+
+def _device_count():
+    from centrifuger_amd import capi
+    import ctypes
+    c = ctypes.c_int(0)
+    capi.lib().cfr_device_count(ctypes.byref(c))
+    return c.value
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs at least two MI355X in the box (the round-end 8-GPU node has them)")
+def test_cli_over_distinct_devices(golden_dir):
+    """--gpu all / --gpu 0,1 on DISTINCT ordinals (CentrifugerClass.cpp:681-694: the per-batch fan-out this library replaces becomes
+    one worker and one index image per GPU): rows in input order, equal to the reference's TSV, whichever device served a batch."""
+    want = open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
+    base = [CLI, "-x", os.path.join(golden_dir, "f6"), "-1", os.path.join(golden_dir, "pe_1.fq"), "-2", os.path.join(golden_dir, "pe_2.fq"), "-k", "5", "--gpu-batch", "20", "-t", "4"]
+    last = str(_device_count() - 1)
+    for gpus in ("all", "0,1", last + ",0"):
+        out = subprocess.run(base + ["--gpu", gpus], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert out == want, gpus
+    want_se = open(os.path.join(GOLDEN, "tsv", "f6.se_default.tsv"), "rb").read()
+    out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq"), "--gpu", "all", "--gpu-batch", "30", "--gpu-throughput"],
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert out == want_se

@@ -292,6 +292,22 @@ def test_resident_entries_wide_and_compact(world, k):
     assert cres["flags"][0] & capi.COMPACT_WIDE
     with pytest.raises(ValueError):
         capi.expand_compact(cres, cmat, k)
+    # ... and the flagged read alone is handed out in the wide layout (cfr_compact_wide_reads): no second pass over a batch.
+    # A batch of ordinary reads with the 70 kbp read in the middle: everything equals the wide entry, the one read patched in
+    mix_b = np.concatenate([b[:int(o[1000])], ex, b[int(o[1000]):int(o[2000])]])
+    mix_o = np.concatenate([o[:1001], [o[1000] + L], o[1001:2001] + L]).astype(np.uint64)
+    dm, om = up(mix_b, np.uint8), up(mix_o.astype(np.int64), np.int64)
+    torch.cuda.synchronize()
+    nm = len(mix_o) - 1
+    cres, cmat = dev.classify_resident_compact(dm.data_ptr(), om.data_ptr(), nm, int(mix_o[-1]))
+    widx, wres2, wmat2 = dev.compact_wide()
+    assert list(widx) == [1000] and int(wres2["score"][0]) == (L - 15) ** 2
+    assert int((cres["flags"] & capi.COMPACT_WIDE).sum()) == 1
+    full_r, full_m = dev.classify_resident(dm.data_ptr(), om.data_ptr(), nm, int(mix_o[-1]))
+    assert digest(*canon(*capi.expand_compact(cres, cmat, k, wide=(widx, wres2, wmat2)), k)) == digest(*canon(full_r, full_m, k))
+    # unused match slots of the compact layout are zero
+    used = np.arange(k)[None, :] < cres["n_match"][:, None]
+    assert not cmat.view(np.uint8).reshape(nm, k, 12)[~used].any()
     dev.close()
 
 
