@@ -283,6 +283,100 @@ struct MappedFile {
   }
 };
 
+// Cuts at given RECORD numbers (pairs: both mate files must be cut at the same record, an interleaved file at an even one).
+// The structure has to be regular for that - 4-line FASTQ (record r starts at line 4 r), or FASTA where every record starts
+// with a '>' line: lines (FASTQ) or '>' lines (FASTA) are counted per chunk by several threads, then the wanted records are
+// located inside their chunks.  Every cut is verified as a record start, the parsers check that a piece holds exactly the
+// records it was cut for, and the caller falls back to the sequential reader when the file is not of that shape.
+// every: records per piece.  cuts: byte offsets of records 0, every, 2 every, ... and the file size.  total: records in the file.
+inline bool plan_record_cuts(const MappedFile &mf, size_t every, int threads, std::vector<size_t> &cuts, size_t &total) {
+  const char fmt = mf.base[0];
+  const bool fastq = fmt == '@';
+  const size_t chunk = 32u << 20;
+  const size_t nchunks = (mf.size + chunk - 1) / chunk;
+  std::vector<size_t> units(nchunks + 1, 0);          // FASTQ: newlines in the chunk; FASTA: lines that start with '>'
+  {
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, threads), nchunks);
+    for (int t = 0; t < nt; ++t) th.emplace_back([&]() {
+      std::vector<char> buf(chunk + 1);
+      for (;;) {
+        const size_t k = next.fetch_add(1);
+        if (k >= nchunks) return;
+        const size_t lo = k * chunk, len = std::min(chunk, mf.size - lo);
+        // one byte before the chunk decides whether its first byte starts a line
+        const size_t from = lo ? lo - 1 : 0, want = len + (lo ? 1 : 0);
+        size_t got = 0;
+        while (got < want) {
+          const ssize_t r = pread(mf.fd, buf.data() + got, want - got, (off_t)(from + got));
+          if (r <= 0) break;
+          got += (size_t)r;
+        }
+        if (got < want) { units[k + 1] = (size_t)-1; continue; }
+        const char *p = buf.data() + (lo ? 1 : 0);
+        size_t c = 0;
+        if (fastq) { for (size_t i = 0; i < len; ++i) c += p[i] == '\n'; }
+        else {
+          if (p[0] == '>' && (lo == 0 || buf[0] == '\n')) ++c;
+          for (size_t i = 1; i < len; ++i) c += (p[i] == '>') & (p[i - 1] == '\n');
+        }
+        units[k + 1] = c;
+      }
+    });
+    for (auto &x : th) x.join();
+  }
+  for (size_t k = 0; k < nchunks; ++k) { if (units[k + 1] == (size_t)-1) return false; units[k + 1] += units[k]; }
+  size_t lines = units[nchunks];
+  if (fastq) {
+    if (mf.base[mf.size - 1] != '\n') ++lines;
+    if (lines % 4) return false;
+    total = lines / 4;
+  } else total = lines;
+  auto verified = [&](size_t at) -> bool {
+    if (at >= mf.size) return at == mf.size;
+    if (mf.base[at] != fmt || (at && mf.base[at - 1] != '\n')) return false;
+    if (!fastq) return true;
+    const char *l1 = (const char *)memchr(mf.base + at, '\n', mf.size - at);
+    if (!l1) return false;
+    const char *l2 = (const char *)memchr(l1 + 1, '\n', mf.size - (size_t)(l1 + 1 - mf.base));
+    return l2 && (size_t)(l2 + 1 - mf.base) < mf.size && l2[1] == '+';
+  };
+  cuts.clear();
+  for (size_t rec = 0; rec < total; rec += every) {
+    const size_t unit = fastq ? 4 * rec : rec;          // FASTQ: the record starts behind newline number `unit`; FASTA: at '>' line number `unit`
+    if (fastq && unit == 0) { cuts.push_back(0); continue; }
+    // FASTQ: the chunk that holds newline number `unit` (units[k] < unit <= units[k + 1]); FASTA: the chunk with '>' line number `unit`
+    const size_t k = fastq ? (size_t)(std::lower_bound(units.begin(), units.end(), unit) - units.begin()) - 1
+                           : (size_t)(std::upper_bound(units.begin(), units.end(), unit) - units.begin()) - 1;
+    if (k >= nchunks) return false;
+    size_t at = k * chunk, have = units[k];
+    const size_t end = std::min(mf.size, at + chunk + 1);     // (+ 1: the record may start on the first byte of the next chunk)
+    size_t pos = (size_t)-1;
+    if (fastq) {
+      // the byte behind newline number `unit` (1-based count of newlines seen = unit)
+      while (have < unit && at < end) {
+        const char *nl = (const char *)memchr(mf.base + at, '\n', end - at);
+        if (!nl) break;
+        ++have;
+        at = (size_t)(nl - mf.base) + 1;
+      }
+      if (have == unit) pos = at;
+    } else {
+      while (at < end) {
+        if (mf.base[at] == '>' && (at == 0 || mf.base[at - 1] == '\n')) { if (have == unit) { pos = at; break; } ++have; }
+        const char *nl = (const char *)memchr(mf.base + at, '\n', end - at);
+        if (!nl) break;
+        at = (size_t)(nl - mf.base) + 1;
+      }
+    }
+    if (pos == (size_t)-1 || !verified(pos)) return false;
+    cuts.push_back(pos);
+  }
+  cuts.push_back(mf.size);
+  return !cuts.empty() && cuts[0] == 0;
+}
+
 struct Batch {
   size_t seq_no = 0;
   size_t n = 0;
@@ -521,6 +615,30 @@ int main(int argc, char *argv[]) {
       }
       return 0;
     }
+    if (atoi(e) == 4 && paired) {   // the pair cutter (plan_record_cuts): pieces of CFR_CLI_PIECE_RECORDS pairs, records piece by piece
+      const size_t every = getenv("CFR_CLI_PIECE_RECORDS") ? strtoull(getenv("CFR_CLI_PIECE_RECORDS"), nullptr, 10) : 7;
+      MappedFile f1, f2;
+      std::vector<size_t> c1, c2;
+      size_t t1 = 0, t2 = 0;
+      bool ok = interleaved ? (f1.open_plain(opt.inter[0]) && plan_record_cuts(f1, 2 * every, 3, c1, t1) && t1 % 2 == 0)
+                            : (f1.open_plain(opt.m1[0]) && f2.open_plain(opt.m2[0]) && plan_record_cuts(f1, every, 3, c1, t1) && plan_record_cuts(f2, every, 3, c2, t2) && t1 == t2);
+      if (!ok) { puts("NOT_CUTTABLE"); return 0; }
+      for (size_t k = 0; k + 1 < c1.size(); ++k) {
+        SeqReader rd1(f1.base + c1[k], c1[k + 1] - c1[k]);
+        std::unique_ptr<SeqReader> rd2;
+        if (!interleaved) rd2.reset(new SeqReader(f2.base + c2[k], c2[k + 1] - c2[k]));
+        size_t got = 0;
+        for (;;) {
+          ids.clear(); s1.clear(); s2.clear(); q.clear();
+          if (!(rd1.next_start() < c1[k + 1] - c1[k] && rd1.next_mem(&ids, s1, &q, hq))) break;
+          if (!(interleaved ? rd1.next_mem(nullptr, s2, nullptr, hq2) : rd2->next_mem(nullptr, s2, nullptr, hq2))) { puts("MATE_MISSING"); break; }
+          printf("%s\t%.*s\t%.*s\t%s%.*s\n", ids.data(), (int)s1.size(), (const char *)s1.data(), (int)s2.size(), (const char *)s2.data(), hq ? "q:" : "-", (int)q.size(), q.data());
+          ++got;
+        }
+        if (k + 2 < c1.size() && got != every) puts("PIECE_SIZE_MISMATCH");
+      }
+      return 0;
+    }
     if (atoi(e) == 2) {       // count only (parser throughput)
       size_t nrec = 0, nbase = 0;
       const auto tp = tick();
@@ -608,8 +726,9 @@ int main(int argc, char *argv[]) {
                                    : r1->next(&b.ids, b.bases1, keep_qual ? &b.qual1 : nullptr, hq);
       if (!ok1) return false;
       if (paired) {
-        const bool ok = interleaved ? r1->next(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2)
-                                    : r2->next(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2);
+        SeqReader *rm = interleaved ? r1 : r2;
+        const bool ok = from_memory ? rm->next_mem(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2)
+                                    : rm->next(nullptr, b.bases2, keep_qual ? &b.qual2 : nullptr, hq2);
         if (!ok) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
         b.offs2.push_back(b.bases2.size());
         if (keep_qual) { b.q2_off.push_back(b.qual2.size()); b.has_qual2.push_back(hq2 ? 1 : 0); }
@@ -687,6 +806,83 @@ int main(int argc, char *argv[]) {
       for (auto &x : th) x.join();
       seq_no += nchunks;
     };
+    // Pairs from plain files: both mate files (or the interleaved file) are cut at the same RECORD numbers (plan_record_cuts)
+    // and the pieces parsed by several threads; a piece that does not hold exactly the records it was cut for stops the run
+    // (never a silent shift between mates).
+    auto read_parallel_pairs = [&](const MappedFile &f1, const std::vector<size_t> &c1, const MappedFile *f2, const std::vector<size_t> &c2,
+                                   size_t total_pairs) {
+      const size_t nchunks = c1.size() - 1;
+      std::atomic<size_t> next_chunk{0};
+      size_t publish_next = 0;
+      const int workers = std::max(1, std::min<int>(opt.parse_threads > 0 ? opt.parse_threads : std::min(opt.threads, 8), (int)nchunks));
+      std::vector<std::thread> th;
+      for (int w = 0; w < workers; ++w) th.emplace_back([&]() {
+        std::vector<char> p1, p2;
+        auto fetch = [&](const MappedFile &mf, size_t lo, size_t hi, std::vector<char> &dst) {
+          const size_t span = hi - lo;
+          if (dst.size() < span) dst.resize(span + (span >> 3));
+          for (size_t got = 0; got < span;) {
+            const ssize_t r = pread(mf.fd, dst.data() + got, span - got, (off_t)(lo + got));
+            if (r <= 0) { print_log("ERROR: cannot read the read file."); exit(EXIT_FAILURE); }
+            got += (size_t)r;
+          }
+          return span;
+        };
+        for (;;) {
+          const size_t k = next_chunk.fetch_add(1);
+          if (k >= nchunks) return;
+          const auto tp = tick();
+          std::shared_ptr<Batch> b = fresh_batch();
+          const size_t want = std::min(opt.gpu_batch, total_pairs - k * opt.gpu_batch);
+          const size_t s1 = fetch(f1, c1[k], c1[k + 1], p1);
+          SeqReader rd1(p1.data(), s1);
+          if (f2) {
+            const size_t s2 = fetch(*f2, c2[k], c2[k + 1], p2);
+            SeqReader rd2(p2.data(), s2);
+            while (b->n < want && take(*b, &rd1, &rd2, true)) {}
+            if (b->n != want || rd1.next_start() < s1 || rd2.next_start() < s2) {
+              print_log("ERROR: the mate files are not made of regular records around pair %lu; rerun with --parse-threads 1.", (unsigned long)(k * opt.gpu_batch + b->n));
+              exit(EXIT_FAILURE);
+            }
+          } else {
+            while (b->n < want && take(*b, &rd1, nullptr, true)) {}
+            if (b->n != want || rd1.next_start() < s1) {
+              print_log("ERROR: the interleaved file is not made of regular records around pair %lu; rerun with --parse-threads 1.", (unsigned long)(k * opt.gpu_batch + b->n));
+              exit(EXIT_FAILURE);
+            }
+          }
+          clk.add(T_PARSE, tp);
+          note_size(*b);
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&]() { return publish_next == k && in_order.size() < max_inflight; });
+          if (b->n) { pending.push_back(b); in_order.push_back(b); }
+          ++publish_next;
+          cv.notify_all();
+        }
+      });
+      for (auto &x : th) x.join();
+      seq_no += nchunks;
+    };
+    bool pairs_done = false;
+    if (paired && opt.parse_threads != 1 && (interleaved ? opt.inter.size() == 1 : (opt.m1.size() == 1 && opt.m2.size() == 1))) {
+      MappedFile f1, f2;
+      std::vector<size_t> c1, c2;
+      size_t t1 = 0, t2 = 0;
+      const int pt = opt.parse_threads > 0 ? opt.parse_threads : std::min(opt.threads, 8);
+      if (interleaved) {
+        if (opt.inter[0] != "-" && f1.open_plain(opt.inter[0]) && plan_record_cuts(f1, 2 * opt.gpu_batch, pt, c1, t1) && t1 % 2 == 0 && c1.size() >= 3) {
+          read_parallel_pairs(f1, c1, nullptr, c2, t1 / 2);
+          pairs_done = true;
+        }
+      } else if (opt.m1[0] != "-" && opt.m2[0] != "-" && f1.open_plain(opt.m1[0]) && f2.open_plain(opt.m2[0]) &&
+                 plan_record_cuts(f1, opt.gpu_batch, pt, c1, t1) && plan_record_cuts(f2, opt.gpu_batch, pt, c2, t2) && c1.size() >= 3) {
+        if (t1 != t2) { print_log("ERROR: The two mate-pair read files have different number of reads."); exit(EXIT_FAILURE); }
+        read_parallel_pairs(f1, c1, &f2, c2, t1);
+        pairs_done = true;
+      }
+    }
+    if (pairs_done) {
+    } else
     if (!paired && opt.parse_threads != 1) {
       for (const std::string &f : opt.u) {
         MappedFile mf;

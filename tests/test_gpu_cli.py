@@ -135,3 +135,28 @@ def test_cli_over_distinct_devices(golden_dir):
     out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-u", os.path.join(golden_dir, "se.fq"), "--gpu", "all", "--gpu-batch", "30", "--gpu-throughput"],
                          check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert out == want_se
+
+
+def test_cli_parallel_reader_of_paired_and_interleaved_plain_files(golden_dir, tmp_path):
+    """-1/-2 and -i from plain files: both mate files are cut at the same record numbers and parsed by several threads
+    (ReadFiles.hpp:337 reads them with one thread); rows must equal the reference's TSV whatever the piece size and thread count,
+    and --parse-threads 1 (the sequential reader) must agree."""
+    want = open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
+    m1, m2 = os.path.join(golden_dir, "pe_1.fq"), os.path.join(golden_dir, "pe_2.fq")
+    l1 = open(m1, "rb").read().split(b"\n")
+    l2 = open(m2, "rb").read().split(b"\n")
+    inter = []
+    for i in range(0, len(l1) - 1, 4):
+        inter += l1[i:i + 4] + l2[i:i + 4]
+    p = tmp_path / "inter.fq"
+    p.write_bytes(b"\n".join(inter) + b"\n")
+    for extra in (["--parse-threads", "5", "--gpu-batch", "17"], ["--parse-threads", "1", "--gpu-batch", "17"], ["--gpu-batch", "64", "-t", "8"]):
+        out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-1", m1, "-2", m2, "-k", "5"] + extra, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert out == want, extra
+        out = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-i", str(p), "-k", "5"] + extra, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert out == want, extra
+    # mates of different counts are an error, as in the reference
+    short = tmp_path / "short_2.fq"
+    short.write_bytes(b"\n".join(l2[:4 * 150]) + b"\n")
+    r = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-1", m1, "-2", str(short), "--gpu-batch", "17"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"different number of reads" in r.stderr

@@ -323,6 +323,28 @@ def test_cli_read_parser(tmp_path, gz):
     oi = subprocess.run([cli, "-x", "unused", "-i", str(tmp_path / "inter.fq")], env=env, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     want = b"".join(a[0] + b"\t" + a[1] + b"\t" + b[1] + b"\tq:" + a[2] + b"\n" for a, b in zip(r1, r2))
     assert o2 == want and oi == want
+    # the pair cutter (both mate files cut at the same record numbers, the interleaved file at even ones; plain files of regular
+    # shape only): pieces of 7 pairs give the same records; FASTA pairs too; irregular files are declared not cuttable
+    for every in ("7", "1", "50", "64"):
+        env4 = dict(os.environ, CFR_CLI_PARSE_ONLY="4", CFR_CLI_PIECE_RECORDS=every)
+        p2 = subprocess.run([cli, "-x", "unused", "-1", str(tmp_path / "m1.fq"), "-2", str(tmp_path / "m2.fq")], env=env4, check=True,
+                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        pi = subprocess.run([cli, "-x", "unused", "-i", str(tmp_path / "inter.fq")], env=env4, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert p2 == want and pi == want, every
+    fa1 = b"".join(b">p%d/1\n%s\n%s\n" % (i, r1[i][1][:30], r1[i][1][30:]) for i in range(50))        # multi-line FASTA records
+    fa2 = b"".join(b">p%d/2\n%s\n" % (i, r2[i][1]) for i in range(50))[:-1]                            # no trailing newline
+    (tmp_path / "m1.fa").write_bytes(fa1)
+    (tmp_path / "m2.fa").write_bytes(fa2)
+    wantfa = b"".join(a[0] + b"\t" + a[1] + b"\t" + b[1] + b"\t-\n" for a, b in zip(r1, r2))
+    pfa = subprocess.run([cli, "-x", "unused", "-1", str(tmp_path / "m1.fa"), "-2", str(tmp_path / "m2.fa")], env=dict(os.environ, CFR_CLI_PARSE_ONLY="4", CFR_CLI_PIECE_RECORDS="9"),
+                         check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert pfa == wantfa
+    (tmp_path / "m1_multi.fq").write_bytes(b"@m1\nACGT\nACGT\n+\nIIII\nIIII\n@m2\nAC\n+\nII\n" * 10)   # multi-line FASTQ: 10 lines per two records
+    (tmp_path / "m2_short.fq").write_bytes(m2[:len(m2) // 2 + 3])
+    for a_, b_ in (("m1_multi.fq", "m2.fq"), ("m1.fq", "m2_short.fq")):
+        bad = subprocess.run([cli, "-x", "unused", "-1", str(tmp_path / a_), "-2", str(tmp_path / b_)], env=dict(os.environ, CFR_CLI_PARSE_ONLY="4"),
+                             check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        assert bad.startswith(b"NOT_CUTTABLE"), (a_, b_)
 
 
 def test_index_written_before_the_end_marker_field(golden_dir, tmp_path, oracle_bin):
