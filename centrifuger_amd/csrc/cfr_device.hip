@@ -95,6 +95,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&dust_stream_, hipStreamNonBlocking));
+  for (auto &e : copied_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   {
     // its own priority class: streams of one class share a few hardware queues round-robin, and a post-stage stream that
     // lands on the search stream's queue runs behind it instead of beside it (seen with the third image of a process)
@@ -162,8 +164,20 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     view_.prot.enabled = 1;
     view_.prot.sigma = P.sigma;
     view_.prot.bits = P.bits;
-    view_.prot.planes = upload(planes);
-    view_.prot.counts = upload(counts);
+    view_.prot.rec = nullptr; view_.prot.planes = nullptr; view_.prot.counts = nullptr;
+    const bool one_line = h.n < 0xffffffffull && P.sigma <= 22 && !(dbg_env("CFR_PROT_TWO_ARRAYS") && atoi(dbg_env("CFR_PROT_TWO_ARRAYS")));
+    if (one_line) {                      // counts and planes of a block in one 128-byte record (cfr_device.hpp)
+      std::vector<uint64_t> rec(nblk * 16, 0);
+      for (uint64_t blk = 0; blk < nblk; ++blk) {
+        uint32_t *c32 = reinterpret_cast<uint32_t *>(&rec[blk * 16]);
+        for (uint32_t k = 0; k < 22; ++k) c32[k] = (uint32_t)counts[blk * 32 + k];
+        for (int k = 0; k < 5; ++k) rec[blk * 16 + 11 + (uint64_t)k] = planes[blk * 8 + (uint64_t)k];
+      }
+      view_.prot.rec = upload(rec);
+    } else {
+      view_.prot.planes = upload(planes);
+      view_.prot.counts = upload(counts);
+    }
     view_.prot.endmarker_bits = (uint32_t)P.end_marker_bits;
     view_.prot.endmarker_n = P.end_marker_n;
     view_.prot.endmarker = upload(P.end_marker_words.empty() ? std::vector<uint64_t>(2, 0) : P.end_marker_words);
@@ -382,6 +396,28 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       view_.ftabx_e8 = e8 ? 1 : 0;
     } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; view_.ftabx_e8 = 0; }   // optional table: run without it
   }
+  if (protein && view_.ftab_width > 0) {
+    // derived K-mer table of a protein index: key in base sigma; K = log_sigma(n) + 1 (a random K-mer of a frame or strand that does
+    // not match then ends inside the lookup), wider than the on-disk ftab, at most 7 (21^7 entries = 29 GB) and a quarter of the free HBM
+    uint32_t K = 1;
+    { double x = (double)h.n; while (x >= (double)h.prot.sigma && K < 12) { x /= (double)h.prot.sigma; ++K; } }
+    K = std::min<uint32_t>(std::max<uint32_t>(K + 1, view_.ftab_width + 1), 7);
+    auto entries_of = [&](uint32_t k) { uint64_t e = 1; for (uint32_t i = 0; i < k; ++i) e *= h.prot.sigma; return e; };
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) while (K > view_.ftab_width + 1 && entries_of(K) * 16 > free_b / 4) --K;
+    if (fast_load) K = 0;
+    if (opt.ftabx_width >= 0) K = std::min<uint32_t>((uint32_t)opt.ftabx_width, 7);
+    if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = std::min<uint32_t>((uint32_t)atoi(e), 7);
+    if (K > view_.ftab_width) try {
+      const uint64_t entries = entries_of(K);
+      uint64_t *d_tab = dev_alloc<uint64_t>(entries * 2 + 2);
+      k_build_ftabx_prot<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, K, entries, d_tab);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      view_.ftabx = d_tab;
+      view_.ftabx_width = K;
+    } catch (const HipError &) { (void)hipGetLastError(); view_.ftabx = nullptr; view_.ftabx_width = 0; }
+  }
   lap("side tables + ftabx");
   // derived text-mode tables: SA / 2-bit text by list ranking, then the step function of the locate values
   if (text_want) {
@@ -555,10 +591,12 @@ void DeviceIndex::release() {            // idempotent: also the clean-up of a c
   for (auto &e : tail_done_) drop_event(e);
   for (auto &e : copy_done_) drop_event(e);
   for (auto &e : h2d_done_) drop_event(e);
+  for (auto &e : copied_) drop_event(e);
   for (auto &e : search_done_) drop_event(e);
   auto drop_stream = [](hipStream_t &s) { if (s) (void)hipStreamDestroy(s); s = nullptr; };
   drop_stream(tail_stream_);
   drop_stream(h2d_stream_);
+  drop_stream(dust_stream_);
   drop_stream(copy_stream_);
   drop_stream(stream_);
 }
@@ -1105,10 +1143,16 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     };
     one(src->b1, src->o1, d_b1);
     if (paired) one(src->b2, src->o2, d_b2);
-    if (dust_ && !view_.prot.enabled) {       // masked on the copy stream, under the kernels of the previous piece
-      dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, h2d_stream_);
-      if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, h2d_stream_);
-    }
+    if (dust_ && !view_.prot.enabled) {
+      // masked on a stream of its own, behind the piece's copy: the copy stream goes straight on with the next piece (the link
+      // is what bounds this entry: 187 MB per piece at ~47 GB/s = 4 ms, the mask kernel 1.1-1.4 ms - on the copy stream
+      // itself every piece paid both)
+      HIP_CHECK(hipEventRecord(copied_[k], h2d_stream_));
+      HIP_CHECK(hipStreamWaitEvent(dust_stream_, copied_[k], 0));
+      dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, dust_stream_);
+      if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, dust_stream_);
+      HIP_CHECK(hipEventRecord(h2d_done_[k], dust_stream_));
+    } else
     HIP_CHECK(hipEventRecord(h2d_done_[k], h2d_stream_));
     have_piece[k] = 1;
   };

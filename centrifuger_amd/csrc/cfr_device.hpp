@@ -54,9 +54,12 @@ struct RbView {
 };
 
 // Protein image (FMIndex<Sequence_RunBlockOneTree>, sigma = 21): the decoded BWT as five bit planes per 64 symbols plus the
-// per-block symbol counts, so that Rank(c, p) = one count + one 40-byte plane group (two gathers) and Access = the planes.
+// per-block symbol counts.  n < 2^32 (and sigma <= 22): ONE 128-byte record per 64 symbols - 22 u32 counts (88 bytes) + the five
+// planes (40 bytes) - so that Rank(c, p) and Access(p) touch one line (one fabric request).  Larger texts: the planes and u64
+// counts in two arrays (two gathers per rank).
 struct ProtView {
   uint32_t enabled, sigma, bits, endmarker_bits;
+  const uint64_t *rec;       // 16 u64 per 64 symbols: u32 counts[22] (count of `code` in B[0, 64 blk)), then planes at word 11; nullptr: the two arrays below
   const uint64_t *planes;    // 8 u64 per 64 symbols: plane k = bit k of the plain code of every symbol (5 used)
   const uint64_t *counts;    // counts[blk * 32 + code] = number of `code` in B[0, 64 blk)
   const uint64_t *endmarker; // endMarkerSA (FixedSizeElemArray words): the sequence id stored at row i < endmarker_n
@@ -223,12 +226,12 @@ class DeviceIndex {
   static constexpr size_t kMaxSub = 16;
   hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 around the search, 8 and 3-7 around the stages behind it
   hipEvent_t *ev_ = nullptr;
-  hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr, tail_stream_ = nullptr;
+  hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr, tail_stream_ = nullptr, dust_stream_ = nullptr;
   hipEvent_t search_done_[2] = {};
   int tail_overlap_mode_ = -1;           // the post stage of a sub-batch beside the search of the next one: -1 = by heavy_frac_, 0 / 1
   double heavy_frac_ = 0.0;              // share of the last call's reads that k_tail_heavy folded
   int tail_blocks_per_cu_ = 0;           // blocks per CU of the post stage when it runs beside a search (0: one lane per read)
-  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {};
+  hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {}, copied_[kMaxSub] = {};
   size_t sub_batch_ = 1250000, taper_floor_ = 262144;
   uint64_t piece_bases_max_ = 12000000000ull;   // bases a sub-batch may hold (its raw hit lists must fit beside the image)
   int num_cus_ = 256, blocks_per_cu_ = 7;
