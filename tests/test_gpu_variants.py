@@ -81,3 +81,17 @@ def test_many_strain_workload_under_switches(name, extra):
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, f"{name}:\n{tail}"
     assert " passed" in tail
+
+
+@pytest.mark.parametrize("name,extra", [("protein_two_arrays", {"CFR_PROT_TWO_ARRAYS": "1"}), ("protein_no_kmer_table", {"CFR_FTABX_WIDTH": "0"}),
+                                        ("protein_kmer_table_3", {"CFR_FTABX_WIDTH": "3"}), ("protein_kmer_table_5_two_arrays", {"CFR_FTABX_WIDTH": "5", "CFR_PROT_TWO_ARRAYS": "1"})])
+def test_protein_suite_under_switches(name, extra):
+    """tests/test_gpu_protein.py with the protein image's other forms: counts and planes in two arrays (what texts of 2^32 symbols
+    and more get) instead of one 128-byte record per block, and the derived K-mer table off / at other widths."""
+    env = dict(os.environ, CFR_DEBUG_ENV="1")
+    env.update(extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_protein.py"), "-m", "gpu", "-x", "-q"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ROOT)
+    tail = r.stdout.decode()[-1500:]
+    assert r.returncode == 0, f"{name}:\n{tail}"
+    assert " passed" in tail
