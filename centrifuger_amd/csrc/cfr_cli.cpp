@@ -477,6 +477,8 @@ struct ReadDump {
       fp[0] = gzopen((prefix + ".fq.gz").c_str(), "w1");
     }
   }
+  // (gzprintf, like ResultWriter.hpp:254-265: zlib formats into its 8192-byte buffer and writes NOTHING for a record that does
+  // not fit - the reference's dumps silently lack reads of ~8 kbp and more, and so do these; tests/test_gpu_cli.py)
   void put(int k, const char *id, const uint8_t *s, size_t n, const char *q, size_t qn) {
     if (!fp[k]) return;
     if (!q) gzprintf(fp[k], ">%s\n%.*s\n", id, (int)n, (const char *)s);

@@ -57,7 +57,112 @@ def reads(rng):
     return out
 
 
+def reads2(rng):
+    """Second set (round 3): what the first one is thin on - runs of non-symbols of every length around the window size at every
+    offset of a read (a run of more than 64 closes a segment, Dustmasker.hpp / CentrifugerClass.cpp:283-289), runs at the ends,
+    low complexity right behind a run, long reads (1-8 kbp) made of random, biased, tandem and homopolymer stretches."""
+    out = []
+
+    def rnd(L):
+        return ACGT[rng.integers(0, 4, size=L)]
+    base = rnd(300)
+    for run in (1, 2, 3, 62, 63, 64, 65, 66, 67, 128, 129, 200):
+        for off in range(0, 70):
+            r = base.copy()
+            r[off:off + run] = ord("N")
+            out.append(r[:max(off + run + 5, 150 + (off % 7))].copy() if off % 3 else r)
+    for run in (1, 5, 64, 65, 70):                                               # runs at the very start / end, and the whole read
+        r = rnd(200).copy(); r[:run] = ord("N"); out.append(r)
+        r = rnd(200).copy(); r[-run:] = ord("N"); out.append(r)
+        out.append(np.full(run, ord("N"), dtype=np.uint8))
+    for k in range(400):                                                         # low complexity directly behind / in front of a run
+        L = int(rng.integers(100, 400))
+        r = rnd(L).copy()
+        a = int(rng.integers(0, L - 80))
+        run = int(rng.choice([1, 3, 10, 63, 64, 65, 66]))
+        r[a:a + run] = ord("N")
+        b = min(L, a + run)
+        fill = int(rng.integers(8, 60))
+        r[b:b + fill] = np.resize(rnd(int(rng.integers(1, 4))), min(fill, L - b))
+        if k % 2:
+            r[max(0, a - fill):a] = np.resize(rnd(int(rng.integers(1, 4))), a - max(0, a - fill))
+        out.append(r)
+    for k in range(60):                                                          # long reads of mixed stretches
+        parts = []
+        total = int(rng.integers(1000, 7000))               # (the reference's gzprintf drops dump records of 8192 bytes and more)
+        while sum(len(p) for p in parts) < total:
+            kind = int(rng.integers(0, 6))
+            L = int(rng.integers(20, 600))
+            if kind == 0:
+                parts.append(rnd(L))
+            elif kind == 1:
+                parts.append(ACGT[rng.choice(4, size=L, p=[0.8, 0.1, 0.05, 0.05])])
+            elif kind == 2:
+                parts.append(np.resize(rnd(int(rng.integers(1, 8))), L))
+            elif kind == 3:
+                parts.append(np.full(int(rng.integers(5, 200)), ACGT[int(rng.integers(0, 4))], dtype=np.uint8))
+            elif kind == 4:
+                parts.append(np.full(int(rng.choice([1, 2, 30, 64, 65, 90])), ord("N"), dtype=np.uint8))
+            else:
+                parts.append(np.frombuffer(bytes(rnd(L)).lower(), dtype=np.uint8))
+        out.append(np.ascontiguousarray(np.concatenate(parts), dtype=np.uint8)[:8100])
+    for k in range(3000):                                                        # 150 bp reads, the bench's length
+        kind = k % 5
+        if kind == 0:
+            r = ACGT[rng.choice(4, size=150, p=[0.6, 0.2, 0.1, 0.1])]
+        elif kind == 1:
+            r = rnd(150).copy(); a = int(rng.integers(0, 120)); r[a:a + int(rng.integers(6, 30))] = ACGT[int(rng.integers(0, 4))]
+        elif kind == 2:
+            r = rnd(150).copy(); a = int(rng.integers(0, 100)); u = rnd(int(rng.integers(2, 5))); n_ = int(rng.integers(10, 50)); r[a:a + n_] = np.resize(u, min(n_, 150 - a))
+        elif kind == 3:
+            r = rnd(150).copy(); r[rng.random(150) < 0.01] = ord("N")
+        else:
+            r = rnd(150)
+        out.append(np.ascontiguousarray(r, dtype=np.uint8))
+    return out
+
+
+def run_reference(rs, fa):
+    tmp = tempfile.mkdtemp(prefix="cfr_dust_")
+    prefix = os.path.join(HERE, "f6")
+    subprocess.run([os.path.join(REF, "centrifuger"), "-x", prefix, "-u", fa, "--un", os.path.join(tmp, "un"), "--cl", os.path.join(tmp, "cl")],
+                   check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    masked = {}
+    for name in ("un.fq.gz", "cl.fq.gz"):
+        lines = gzip.open(os.path.join(tmp, name), "rb").read().split(b"\n")
+        i = 0
+        while i < len(lines):
+            if lines[i].startswith(b">"):
+                masked[lines[i][1:]] = lines[i + 1]
+                i += 2
+            elif lines[i].startswith(b"@"):
+                masked[lines[i][1:]] = lines[i + 1]
+                i += 4
+            else:
+                i += 1
+    return masked
+
+
+def main2():
+    rng = np.random.default_rng(SEED + 1)
+    rs = reads2(rng)
+    tmp = tempfile.mkdtemp(prefix="cfr_dust2_")
+    fa = os.path.join(tmp, "reads2.fa")
+    with open(fa, "wb") as f:
+        for i, r in enumerate(rs):
+            f.write(b">e%d\n%s\n" % (i, r.tobytes()))
+    masked = run_reference(rs, fa)
+    with gzip.GzipFile(os.path.join(OUT, "reads2.fa.gz"), "wb", mtime=0) as f:
+        f.write(open(fa, "rb").read())
+    with gzip.GzipFile(os.path.join(OUT, "masked2_by_reference.fa.gz"), "wb", mtime=0) as f:
+        for i in range(len(rs)):
+            f.write(b">e%d\n%s\n" % (i, masked.get(b"e%d" % i, b"")))
+    print("set 2:", len(rs), "reads;", sum(1 for i, r in enumerate(rs) if masked.get(b"e%d" % i, b"") != r.tobytes()), "masked somewhere")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "set2":
+        return main2()
     rng = np.random.default_rng(SEED)
     os.makedirs(OUT, exist_ok=True)
     rs = [r for r in reads(rng)]

@@ -184,6 +184,19 @@ def test_device_masks_equal_the_reference_dumps(dev):
     assert sum(1 for i in range(len(ids)) if bytes(b[int(o[i]):int(o[i + 1])]) != want[ids[i]]) > 500
 
 
+def test_device_masks_equal_the_second_set_of_reference_dumps(dev):
+    """Set 2 of tests/golden/dust (non-symbol runs of every length around the window at every offset, runs at the ends, low
+    complexity beside a run, long reads of mixed stretches, 3 000 reads of 150 bp): the device scan against what the REFERENCE
+    wrote for them."""
+    from test_host_cpu import _dust_set2
+    _, d = dev
+    ids, b, o, want = _dust_set2()
+    got = b.copy()
+    d.dust_mask(got, o)
+    bad = [ids[i] for i in range(len(ids)) if bytes(got[int(o[i]):int(o[i + 1])]) != want[ids[i]]]
+    assert not bad, bad[:10]
+
+
 def test_one_instantiation_for_all_reads():
     """The same tests with CFR_DUST_SPLIT=0: every read through the 125-triplet instantiation of k_dust (no flag pass, no
     ACGT-only instantiation) - the two forms must mask alike."""

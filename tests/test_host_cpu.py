@@ -454,3 +454,36 @@ def test_host_dust_twins_and_oracle_equal_the_reference_dumps():
         s = bytes(b[int(o[i]):int(o[i + 1])])
         if len(s) < 3000:                      # (the oracle's literal list is slow on the 6 kbp homopolymer; the twins cover it)
             assert ora.dust_mask(s) == want[rid], rid
+
+
+def _dust_set2():
+    import gzip
+    import tempfile
+    raw = gzip.open(os.path.join(ROOT, "tests", "golden", "dust", "reads2.fa.gz"), "rb").read()
+    with tempfile.NamedTemporaryFile(suffix=".fa", delete=False) as f:
+        f.write(raw)
+        path = f.name
+    ids, b, o = ora.read_fastx(path)
+    os.unlink(path)
+    lines = gzip.open(os.path.join(ROOT, "tests", "golden", "dust", "masked2_by_reference.fa.gz"), "rb").read().split(b"\n")
+    want = {lines[i][1:].decode(): lines[i + 1] for i in range(0, len(lines) - 1, 2)}
+    return ids, b, o, want
+
+
+def test_host_dust_twins_equal_the_second_set_of_reference_dumps():
+    """tests/golden/dust set 2 (round 3, tests/golden/make_golden_dust.py set2): 4 300 reads the REFERENCE masked - runs of
+    non-symbols of 1..200 at every offset 0..69 (a run of more than 64 closes a segment), runs at the ends of a read, low
+    complexity directly beside a run, 60 long reads (1-8 kbp) of mixed stretches, 3 000 reads of the bench's 150 bp.  Both host
+    twins reproduce every one of them; the oracle's literal scan is checked on the short ones."""
+    ids, b, o, want = _dust_set2()
+    assert len(ids) == len(want) > 4000
+    assert sum(1 for i, rid in enumerate(ids) if bytes(b[int(o[i]):int(o[i + 1])]) != want[rid]) > 1500      # the set does get masked
+    for literal in (False, True):
+        got = b.copy()
+        capi.dust_mask(got, o, threads=4, literal=literal)
+        bad = [rid for i, rid in enumerate(ids) if bytes(got[int(o[i]):int(o[i + 1])]) != want[rid]]
+        assert not bad, (literal, bad[:10])
+    for i, rid in enumerate(ids[:1500]):
+        s_ = bytes(b[int(o[i]):int(o[i + 1])])
+        if len(s_) < 400:
+            assert ora.dust_mask(s_) == want[rid], rid
