@@ -772,8 +772,8 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
-    sv.wide_rows = kWideRows;
-    if (const char *e = dbg_env("CFR_WIDE_ROWS")) sv.wide_rows = std::min<uint32_t>(kWideRows, (uint32_t)atoi(e));
+    sv.wide_rows = wide_ ? kWideRowsWide : kWideRows;
+    if (const char *e = dbg_env("CFR_WIDE_ROWS")) sv.wide_rows = std::min<uint32_t>(sv.wide_rows, (uint32_t)atoi(e));
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
     // few chains per lane (long reads): chains are handed out dynamically (DYN), one atomic per chain
     bool dyn = nchains < 8ull * blocks * kBlock && (total1 + total2) / std::max<size_t>(1, nchains) >= 500;    // (per chain: half the mean read)
