@@ -770,9 +770,13 @@ def main():
     widen()
     os.sched_setaffinity(0, all_cpus)                    # the CPU legs below (oracle counters, reference baseline) get every core back
 
+    # the ranks part here: nothing below needs the process group (rank 0 goes on alone with the CPU baseline, the live PMC
+    # passes and the sub-results - minutes during which the other ranks must not be held, nor rank 0 wait for them at exit)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
         return
 
     total_reads = args.reads * args.steps * world
