@@ -1105,8 +1105,15 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
   if (compact && !stride) throw HipError{"the compact result layout needs max_result > 0", -2};
   const size_t res_bytes = compact ? sizeof(cfr_result_compact) : sizeof(cfr_result), match_bytes = compact ? sizeof(cfr_match_compact) : sizeof(cfr_match);
-  if (dust_ && !src && !view_.prot.enabled) {          // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
-    // reads already on the device (the caller's buffer stays as it is): mask a private copy
+  // SDUST of reads that are already on the device (the caller's buffer stays as it is: a private copy is masked).  With the
+  // one-launch post stage the copy and the mask kernel of sub-batch k + 1 run on the dust stream beside the search of sub-batch k
+  // - the mask kernel is bound by its own instructions, the search by the fabric - like the streamed host inputs do; otherwise
+  // the whole batch is copied and masked up front.
+  const bool dust_here = dust_ && !src && !view_.prot.enabled;      // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
+  bool dust_pieces = dust_here && !search_v1_ && stride > 0 && one_launch_ready();
+  if (const char *e = dbg_env("CFR_DUST_PIECES")) dust_pieces = dust_pieces && atoi(e) != 0;
+  const uint8_t *orig_b1 = d_b1, *orig_b2 = d_b2;
+  if (dust_here && !dust_pieces) {
     auto masked_copy = [&](size_t slot, const uint8_t *d_b, const uint64_t *d_o, uint64_t total) -> const uint8_t * {
       uint8_t *c = (uint8_t *)scratch(slot, total + 16);
       if (total) HIP_CHECK(hipMemcpyAsync(c, d_b, total, hipMemcpyDeviceToDevice, stream_));
@@ -1115,16 +1122,20 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     };
     d_b1 = masked_copy(S_DUSTTMP, d_b1, d_o1, total1);
     if (d_b2) d_b2 = masked_copy(S_DUSTTMP2, d_b2, d_o2, total2);
+  } else if (dust_pieces) {
+    d_b1 = (const uint8_t *)scratch(S_DUSTTMP, total1 + 16);
+    if (d_b2) d_b2 = (const uint8_t *)scratch(S_DUSTTMP2, total2 + 16);
   }
-  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/src == nullptr);
+  const bool by_piece = src != nullptr || dust_pieces;             // the bases of a sub-batch arrive (and are packed) right before its search
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece);
   size_t sb = 0;
   const auto pieces = cut_pieces(n, stride > 0, sb, total1 + total2);
   const size_t nsub = pieces.size();
   const bool paired = d_b2 != nullptr;
   // bases of every piece (its buffers are sized by them): from the caller's offsets, or 8 bytes per boundary from the device
   std::vector<uint64_t> pt1(nsub, total1), pt2(nsub, total2);
-  if (nsub > 1) {
-    std::vector<uint64_t> b1(nsub + 1, 0), b2(nsub + 1, 0);
+  std::vector<uint64_t> b1(nsub + 1, 0), b2(nsub + 1, 0);          // byte offsets of the pieces' first reads (and of the end)
+  if (nsub > 1 || by_piece) {
     for (size_t k = 0; k <= nsub; ++k) {
       const size_t at = k < nsub ? pieces[k].first : n;
       if (src) { b1[k] = src->o1[at]; if (paired) b2[k] = src->o2[at]; }
@@ -1142,10 +1153,19 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
-  std::vector<uint8_t> have_piece(nsub, src ? 0 : 1);
+  std::vector<uint8_t> have_piece(nsub, by_piece ? 0 : 1);
   auto bring_piece = [&](size_t k) {
-    if (!src || have_piece[k]) return;
+    if (!by_piece || have_piece[k]) return;
     const size_t lo = pieces[k].first, hi = lo + pieces[k].second;
+    if (dust_pieces) {                          // device to device, then the mask kernel, both on the dust stream
+      if (b1[k + 1] > b1[k]) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(d_b1) + b1[k], orig_b1 + b1[k], b1[k + 1] - b1[k], hipMemcpyDeviceToDevice, dust_stream_));
+      if (paired && b2[k + 1] > b2[k]) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(d_b2) + b2[k], orig_b2 + b2[k], b2[k + 1] - b2[k], hipMemcpyDeviceToDevice, dust_stream_));
+      dust_on_device(const_cast<uint8_t *>(d_b1), d_o1 + lo, hi - lo, dust_stream_);
+      if (paired) dust_on_device(const_cast<uint8_t *>(d_b2), d_o2 + lo, hi - lo, dust_stream_);
+      HIP_CHECK(hipEventRecord(h2d_done_[k], dust_stream_));
+      have_piece[k] = 1;
+      return;
+    }
     auto one = [&](const uint8_t *hb, const uint64_t *ho, const uint8_t *db) {
       const uint64_t a = ho[lo], b = ho[hi];
       if (b > a) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
@@ -1166,15 +1186,14 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     have_piece[k] = 1;
   };
   auto pack_piece = [&](size_t k) {            // on the main stream, behind the copy of the piece
-    if (!src) return;
-    const size_t lo = pieces[k].first, hi = lo + pieces[k].second;
+    if (!by_piece) return;
     HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
-    auto one = [&](const uint64_t *ho, const uint8_t *db, uint64_t total, uint64_t *packed) {
-      const uint64_t b0 = ho[lo] >> 4, b1x = (ho[hi] + 15) >> 4;          // the blocks the piece touches (a block shared with the
+    auto one = [&](uint64_t from, uint64_t to, const uint8_t *db, uint64_t total, uint64_t *packed) {
+      const uint64_t b0 = from >> 4, b1x = (to + 15) >> 4;                // the blocks the piece touches (a block shared with the
       if (b1x > b0) k_pack_reads<<<grid_for(b1x - b0), kBlock, 0, stream_>>>(db + (b0 << 4), total - (b0 << 4), b1x - b0, packed + b0);   // next piece is packed again there)
     };
-    one(src->o1, d_b1, total1, packed1_);
-    if (paired) one(src->o2, d_b2, total2, packed2_);
+    one(b1[k], b1[k + 1], d_b1, total1, packed1_);
+    if (paired) one(b2[k], b2[k + 1], d_b2, total2, packed2_);
     HIP_CHECK(hipGetLastError());
   };
   // the post stage beside the next sub-batch's search: pays when the post stage is long (reads over families of strains:
