@@ -1105,13 +1105,14 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};
   if (compact && !stride) throw HipError{"the compact result layout needs max_result > 0", -2};
   const size_t res_bytes = compact ? sizeof(cfr_result_compact) : sizeof(cfr_result), match_bytes = compact ? sizeof(cfr_match_compact) : sizeof(cfr_match);
-  // SDUST of reads that are already on the device (the caller's buffer stays as it is: a private copy is masked).  With the
-  // one-launch post stage the copy and the mask kernel of sub-batch k + 1 run on the dust stream beside the search of sub-batch k
-  // - the mask kernel is bound by its own instructions, the search by the fabric - like the streamed host inputs do; otherwise
-  // the whole batch is copied and masked up front.
+  // SDUST of reads that are already on the device (the caller's buffer stays as it is: a private copy is masked): the whole
+  // batch is copied and masked up front.  The other schedule - copy + mask kernel of sub-batch k + 1 on the dust stream beside the
+  // search of sub-batch k, as the streamed host inputs do - is kept behind CFR_DUST_PIECES=1 because it LOSES here: 31.9 ms per
+  // 10 M reads against 25.8 ms up front (the search kernel issues ~60 % of its VALU slots itself, so the mask kernel beside it
+  // slows both; with host inputs the same overlap pays because the link, not the kernels, bounds the step).
   const bool dust_here = dust_ && !src && !view_.prot.enabled;      // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
-  bool dust_pieces = dust_here && !search_v1_ && stride > 0 && one_launch_ready();
-  if (const char *e = dbg_env("CFR_DUST_PIECES")) dust_pieces = dust_pieces && atoi(e) != 0;
+  bool dust_pieces = false;
+  if (const char *e = dbg_env("CFR_DUST_PIECES")) dust_pieces = dust_here && !search_v1_ && stride > 0 && one_launch_ready() && atoi(e) != 0;
   const uint8_t *orig_b1 = d_b1, *orig_b2 = d_b2;
   if (dust_here && !dust_pieces) {
     auto masked_copy = [&](size_t slot, const uint8_t *d_b, const uint64_t *d_o, uint64_t total) -> const uint8_t * {

@@ -23,6 +23,8 @@ VARIANTS = {
     "lean_image": {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_LOC_MEMO_GB": "0"},
     "lean_image_text_mode_early": {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_FTABX_WIDTH": "8", "CFR_LOC_MEMO_GB": "0", "CFR_TEXT_MIN_L": "8"},
     "no_memo_locate_by_steps": {"CFR_LOC_MEMO_GB": "0"},
+    # SDUST of resident reads sub-batch by sub-batch on the dust stream (the bench's with_device_sdust leg and the CLI use the device mask)
+    "dust_by_pieces": {"CFR_DUST_PIECES": "1", "CFR_SUBBATCH": "64", "CFR_TAPER_FLOOR": "0"},
     "ftabx_8_byte_entries": {"CFR_FTABX_E8": "1", "CFR_FTABX_WIDTH": "12"},
     # the sampled rows "do not follow" the step function: no text mode, locate memo by the plain walk
     "step_function_rejected": {"CFR_STEPS_OFF": "1"},
