@@ -979,6 +979,21 @@ int main(int argc, char *argv[]) {
   // ~30 M reads/s whatever the tables (profiles/r2f_cli_timing.txt): what a run feels is the load time.  --gpu-balanced adds the
   // text-mode tables and the locate memo (+0.4 s per Gbp), --gpu-throughput the 68 GB K-mer table as well.
   dopt.profile = opt.throughput_profile ? CFR_PROFILE_THROUGHPUT : opt.balanced_profile ? CFR_PROFILE_BALANCED : CFR_PROFILE_FAST_LOAD;
+  if (!opt.throughput_profile && !opt.balanced_profile) {
+    // no profile asked for: by the size of the input.  The fast-load image classifies ~30 M reads/s; the text-mode tables of the
+    // balanced image cost ~0.4 s per Gbp of index once and lift that several-fold, which pays from a few GB of reads on (plain
+    // files: bytes on disk; gz: ~4x that when inflated; stdin: unknown, stays fast-load).
+    unsigned long long bytes = 0;
+    for (const auto *lst : {&opt.u, &opt.m1, &opt.m2, &opt.inter})
+      for (const std::string &f : *lst) {
+        struct stat st;
+        if (f != "-" && stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) {
+          const bool gz = f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0;
+          bytes += (unsigned long long)st.st_size * (gz ? 4ull : 1ull);
+        }
+      }
+    if (bytes >= (8ull << 30)) dopt.profile = CFR_PROFILE_BALANCED;
+  }
   for (int g : opt.gpus) {
     cfr_dev_index *d = nullptr;
     st = cfr_device_index_create_ex(idx, g, &dopt, &d);

@@ -24,3 +24,21 @@ if [ -x oracle/_ref/centrifuger ]; then
   ( time oracle/_ref/centrifuger -x $idx -u $big -t 64 > /tmp/ref_big.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
   md5sum /tmp/ref_big.tsv | tee -a $out
 fi
+# ---- pairs: 10 M pairs (-1/-2, -k 5) and the same as one interleaved file; plain files are cut at equal record numbers and parsed in pieces
+python bench.py --mode pe --steps 1 --warmup 1 --no-pmc --no-extra-configs > gpurun_out/cli_bench_pe.json 2> gpurun_out/cli_bench_pe.err
+f1=$(ls /tmp/cfr_bench/*/sample_0.fa 2>/dev/null | head -1); f2=${f1%.fa}_2.fa
+if [ -f "$f2" ]; then
+  for i in 1 2 3 4 5; do cat $f1; done > /tmp/big10m_1.fa
+  for i in 1 2 3 4 5; do cat $f2; done > /tmp/big10m_2.fa
+  for pt in 0 1; do
+    echo "== 10 M pairs -k 5, -t 64 --parse-threads $pt" | tee -a $out
+    ( time CFR_CLI_TIMING=1 centrifuger_amd/bin/centrifuger -x $idx -1 /tmp/big10m_1.fa -2 /tmp/big10m_2.fa -k 5 -t 64 --parse-threads $pt > /tmp/cli_pe.tsv ) 2>&1 | grep -E "timing|real" | tee -a $out
+    md5sum /tmp/cli_pe.tsv | tee -a $out
+  done
+  if [ -x oracle/_ref/centrifuger ]; then
+    echo "== 2 M pairs -k 5: reference -t 64 vs this command line" | tee -a $out
+    ( time oracle/_ref/centrifuger -x $idx -1 $f1 -2 $f2 -k 5 -t 64 > /tmp/ref_pe.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
+    ( time centrifuger_amd/bin/centrifuger -x $idx -1 $f1 -2 $f2 -k 5 -t 64 > /tmp/own_pe.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
+    md5sum /tmp/ref_pe.tsv /tmp/own_pe.tsv | tee -a $out
+  fi
+fi
