@@ -292,7 +292,7 @@ struct MappedFile {
 inline bool plan_record_cuts(const MappedFile &mf, size_t every, int threads, std::vector<size_t> &cuts, size_t &total) {
   const char fmt = mf.base[0];
   const bool fastq = fmt == '@';
-  const size_t chunk = 32u << 20;
+  const size_t chunk = 4u << 20;       // (small chunks: locating a wanted record scans half a chunk line by line)
   const size_t nchunks = (mf.size + chunk - 1) / chunk;
   std::vector<size_t> units(nchunks + 1, 0);          // FASTQ: newlines in the chunk; FASTA: lines that start with '>'
   {
