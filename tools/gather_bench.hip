@@ -1,6 +1,8 @@
 // gather_bench.hip — what random dependent 16-byte gathers cost on this chip (the access pattern of an
 // FM-index step): every lane chases its own pseudo-random chain through a table of 64-byte records.
-//   ./gather_bench <table_MB> <mode> <steps> [lanes]
+//   ./gather_bench <table_MB> <mode> <steps> [lanes] [alloc]
+//   alloc 0 = hipMalloc (default); 1 = one physical allocation mapped through the virtual-memory API (hipMemCreate / hipMemMap,
+//           address reserved with 1 GB alignment): does the table's page size / TLB reach change the gather rate?
 //   mode 1|2|3 : that many loads inside ONE random 64-byte record per step (16 B; 8 B + 16 B; 16 + 16 + 16 B)
 //   mode 4     : two 16-byte loads per step, one in each 64-byte half of ONE random 128-byte aligned line
 //   mode 5     : two 16-byte loads per step in two INDEPENDENT random 64-byte records
@@ -66,7 +68,28 @@ int main(int argc, char **argv) {
   const int steps = argc > 3 ? atoi(argv[3]) : 100;
   const uint64_t lanes = argc > 4 ? strtoull(argv[4], 0, 10) : (uint64_t)256 * 2048 * 8;
   const uint64_t nrec = mb * 1024 * 1024 / 64;
+  const int alloc = argc > 5 ? atoi(argv[5]) : 0;
   uint64_t *tab, *out;
+  if (alloc == 1) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    size_t gran = 0;
+    CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    size_t bytes = ((nrec * 64 + gran - 1) / gran) * gran;
+    hipMemGenericAllocationHandle_t h;
+    CHECK(hipMemCreate(&h, bytes, &prop, 0));
+    void *va = nullptr;
+    CHECK(hipMemAddressReserve(&va, bytes, (size_t)1 << 30, nullptr, 0));
+    CHECK(hipMemMap(va, bytes, 0, h, 0));
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    CHECK(hipMemSetAccess(va, bytes, &acc, 1));
+    tab = (uint64_t *)va;
+    printf("vmm: granularity %zu bytes, va %p\n", gran, va);
+  } else
   CHECK(hipMalloc(&tab, nrec * 64));
   CHECK(hipMalloc(&out, lanes * 8));
   fill<<<4096, 256>>>(tab, nrec * 8);
