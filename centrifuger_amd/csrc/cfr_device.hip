@@ -351,14 +351,15 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   view_.ftabx = nullptr;
   view_.ftabx_width = 0;
   view_.ftabx_e8 = 0;
-  view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
+  view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text8 = nullptr; view_.text_min_l = 0;
   memset(&view_.steps, 0, sizeof(view_.steps));
   uint32_t log4n = 0;
   while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
-  const bool text_possible = h.n >= 64 && h.n < (1ull << 36) && !layout_rb && !protein;
+  // (a protein index: u32 suffix array and one byte of text per symbol, below 2^32 symbols)
+  const bool text_possible = h.n >= 64 && h.n < (protein ? 0xfffffff0ull : (1ull << 36)) && !layout_rb;
   bool text_want = text_possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
   if (const char *e = dbg_env("CFR_TEXT_MODE")) text_want = text_possible && atoi(e) != 0;
-  const double sa_bytes = (double)h.n * (wide_ ? 4.5 : 4.0), text_tab_bytes = sa_bytes + (double)h.n * 0.25;
+  const double sa_bytes = (double)h.n * (wide_ ? 4.5 : 4.0), text_tab_bytes = sa_bytes + (double)h.n * (protein ? 1.0 : 0.25);
   const double ruler_bytes = (double)(h.n >> kRulerShift) * 24.0;
   const double batch_reserve = 12e9;                       // buffers of a 10 M-read batch (raw hits, virtual rows, results)
   {
@@ -445,7 +446,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
         HIP_CHECK(hipMalloc(&q, sa_alloc));
         d_sa = (uint32_t *)q;
       }
-      const uint64_t twords = (h.n + 31) / 32 + 6;
+      const uint64_t twords = protein ? (h.n + 7) / 8 + 8 : (h.n + 31) / 32 + 6;       // protein: a byte per symbol
       {
         void *q = nullptr;
         HIP_CHECK(hipMalloc(&q, twords * 8));
@@ -456,26 +457,42 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       if (wide_) HIP_CHECK(hipMemsetAsync(d_sa, 0, sa_alloc, stream_));                         // 36-bit entries are or-ed into place
       else HIP_CHECK(hipMemsetAsync((char *)d_sa + (size_t)h.n * 4, 0, 256, stream_));
       if (wide_) k_ruler_fill<true><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, (unsigned long long *)d_text);
-      else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, (unsigned long long *)d_text);
+      else k_ruler_fill<false><<<gr, 256, 0, stream_>>>(view_, nrulers, ds_a, d_sa, (unsigned long long *)d_text);      // (protein: bytes from d_text_alloc + 16 on)
       HIP_CHECK(hipGetLastError());
       HIP_CHECK(hipStreamSynchronize(stream_));
       for (void *q : tmp_here) temp_free(q);
       tmp_here.clear();
       if (wide_) view_.sa36 = d_sa; else view_.sa32 = d_sa;
       lap("SA / text (list ranking)");
-      // ---- the step function: breakpoints = position 0 and the selectedSA positions, runs of equal values merged
-      const uint64_t nsel = h.selected_rows.size();
+      // ---- the step function: breakpoints = position 0 and the positions of the rows that store a value of their own - the
+      // selectedSA rows (nucleotide index: one per genome boundary) or the end-marker rows (protein index: the row of every '$',
+      // FMIndex.hpp:224-228) - with runs of equal values merged
+      std::vector<uint64_t> brk_rows, brk_vals;
+      if (protein) {
+        const ProteinPart &P = h.prot;
+        for (uint64_t r = 0; r < P.end_marker_n; ++r) {
+          const uint64_t bit = r * (uint64_t)P.end_marker_bits, w0 = P.end_marker_words[bit >> 6], w1 = P.end_marker_words[(bit >> 6) + 1];
+          const uint32_t sh = (uint32_t)bit & 63u;
+          uint64_t x = w0 >> sh;
+          if (sh) x |= w1 << (64 - sh);
+          if (P.end_marker_bits < 64) x &= (1ull << P.end_marker_bits) - 1;
+          brk_rows.push_back(r);
+          brk_vals.push_back(x);
+        }
+      } else { brk_rows = h.selected_rows; brk_vals = h.selected_vals; }
+      const uint64_t nsel = brk_rows.size();
       std::vector<uint64_t> bpos(nsel + 1, 0);
       if (nsel) {
-        uint64_t *d_p = (uint64_t *)talloc(nsel * 8);
-        k_gather_sa<<<grid_for(nsel), kBlock, 0, stream_>>>(view_, view_.sel_rows, nsel, d_p);
+        uint64_t *d_r = (uint64_t *)talloc(nsel * 8), *d_p = (uint64_t *)talloc(nsel * 8);
+        HIP_CHECK(hipMemcpyAsync(d_r, brk_rows.data(), nsel * 8, hipMemcpyHostToDevice, stream_));
+        k_gather_sa<<<grid_for(nsel), kBlock, 0, stream_>>>(view_, d_r, nsel, d_p);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(bpos.data() + 1, d_p, nsel * 8, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
       }
       std::vector<std::pair<uint64_t, uint64_t>> bp;
       bp.emplace_back(0, h.adjusted_sa0);
-      for (uint64_t g = 0; g < nsel; ++g) if (h.selected_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], h.selected_vals[g]);
+      for (uint64_t g = 0; g < nsel; ++g) if (brk_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], brk_vals[g]);
       std::sort(bp.begin(), bp.end());
       std::vector<uint64_t> spos, sval;
       for (const auto &e : bp) if (spos.empty() || e.second != sval.back()) { spos.push_back(e.first); sval.push_back(e.second); }
@@ -510,8 +527,14 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       if (bad || (dbg_env("CFR_STEPS_OFF") && atoi(dbg_env("CFR_STEPS_OFF")))) throw HipError{"the sampled rows do not follow the step function of the selectedSA positions", -5};
       owned_.push_back(d_sa); device_bytes_ += sa_alloc;
       owned_.push_back(d_text_alloc); device_bytes_ += twords * 8;
-      view_.text2 = d_text;
+      if (protein) view_.text8 = reinterpret_cast<const uint8_t *>(d_text_alloc) + 16;
+      else view_.text2 = d_text;
       view_.text_min_l = log4n + 2;                       // random matches rarely get past log4(n) characters
+      if (protein) {                                      // ... log_sigma(n) for a protein index
+        uint32_t ls = 0;
+        for (double x = (double)h.n; x >= (double)h.prot.sigma; x /= (double)h.prot.sigma) ++ls;
+        view_.text_min_l = ls + 2;
+      }
       if (const char *e = dbg_env("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
       lap("locate step function");
     } catch (const HipError &) {                           // optional tables: run without them, and give back what they took
@@ -520,7 +543,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       for (void *q : tmp_here) temp_free(q);
       if (d_sa) (void)hipFree(d_sa);
       if (d_text_alloc) (void)hipFree(d_text_alloc);
-      view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text_min_l = 0;
+      view_.sa32 = nullptr; view_.sa36 = nullptr; view_.text2 = nullptr; view_.text8 = nullptr; view_.text_min_l = 0;
       memset(&view_.steps, 0, sizeof(view_.steps));       // (the three small step arrays stay owned until the image goes)
     }
   }
@@ -729,7 +752,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
   const uint64_t cap_total = 2 * (total1 / mhl1 + n) + (paired ? 2 * (total2 / mhl1 + n) : 0);
 
-  if (view_.prot.enabled) return launch_search_protein(d_b1, d_o1, d_b2, d_o2, n, total1, total2);
+  if (view_.prot.enabled) return launch_search_protein(d_b1, d_o1, d_b2, d_o2, n, total1, total2, row_space_only);
   // two sets of output buffers: the post stage of sub-batch k (its own stream) reads one while the search of k + 1 fills the other
   uint64_t *cap = (uint64_t *)scratch(par ? S_CAP1 : S_CAP, (n + 1) * 8);
   uint64_t *hit_off = (uint64_t *)scratch(par ? S_HITOFF1 : S_HITOFF, (n + 1) * 8);
@@ -815,7 +838,9 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
 
 // Translated search (Classifier::TranslatedSearch): 6 chains per mate (strand x frame), one lane each
 DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                                          uint64_t total1, uint64_t total2) {
+                                                          uint64_t total1, uint64_t total2, bool row_space_only) {
+  DevView sview = view_;
+  if (row_space_only) sview.text8 = nullptr;             // the hits leave with real BWT rows (no text mode)
   const bool paired = d_b2 != nullptr;
   const size_t nchains = n * (size_t)(paired ? 12 : 6);
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
@@ -835,10 +860,10 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   uint8_t *codes1 = (uint8_t *)scratch(S_PCODES1, 2 * prot_total1_ + 64), *codes2 = paired ? (uint8_t *)scratch(S_PCODES2, 2 * prot_total2_ + 64) : nullptr;
   if (paired) {
     k_translate_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2);
-    k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2);
+    k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2);
   } else {
     k_translate_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr);
-    k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr);
+    k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));

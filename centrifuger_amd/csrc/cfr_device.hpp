@@ -98,6 +98,7 @@ struct DevView {            // passed by value to kernels
   const uint32_t *sa36;     // entry i at bits [36 i, 36 i + 36) of the little-endian bit string
   StepView steps;           // locate as a function of the text position
   const uint64_t *text2;    // symbol p at bits 2(p%32) of word p/32
+  const uint8_t *text8;     // protein index: the text as plain codes, one byte per symbol (16 zero bytes in front); nullptr otherwise
   uint32_t text_min_l;      // a search switches to text comparison once it has matched this many characters
   const uint64_t *sel_rows, *sel_vals;
   uint64_t sel_cnt;
@@ -204,7 +205,7 @@ class DeviceIndex {
   // every row (real or virtual) of a hit can be located by one table access: memo at every row, or SA + step function
   bool locate_direct() const { return (view_.loc_memo && view_.memo_shift == 0) || (have_sa() && view_.steps.pos); }
   SearchBuf launch_search_protein(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
-                                  uint64_t total1, uint64_t total2);
+                                  uint64_t total1, uint64_t total2, bool row_space_only = false);
   void launch_post(const SearchBuf &sb, const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                    bool want_rows, Pipe &p, std::vector<uint64_t> *hit_begin_host, bool fused, hipStream_t st);
   std::vector<std::pair<size_t, size_t>> cut_pieces(size_t n, bool per_read_slots, size_t &sb, uint64_t total_bases = 0) const;
