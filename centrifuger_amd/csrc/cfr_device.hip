@@ -467,19 +467,27 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       // ---- the step function: breakpoints = position 0 and the positions of the rows that store a value of their own - the
       // selectedSA rows (nucleotide index: one per genome boundary) or the end-marker rows (protein index: the row of every '$',
       // FMIndex.hpp:224-228) - with runs of equal values merged
-      std::vector<uint64_t> brk_rows, brk_vals;
+      std::vector<std::pair<uint64_t, uint64_t>> bp;
       if (protein) {
-        const ProteinPart &P = h.prot;
-        for (uint64_t r = 0; r < P.end_marker_n; ++r) {
-          const uint64_t bit = r * (uint64_t)P.end_marker_bits, w0 = P.end_marker_words[bit >> 6], w1 = P.end_marker_words[(bit >> 6) + 1];
-          const uint32_t sh = (uint32_t)bit & 63u;
-          uint64_t x = w0 >> sh;
-          if (sh) x |= w1 << (64 - sh);
-          if (P.end_marker_bits < 64) x &= (1ull << P.end_marker_bits) - 1;
-          brk_rows.push_back(r);
-          brk_vals.push_back(x);
-        }
-      } else { brk_rows = h.selected_rows; brk_vals = h.selected_vals; }
+        // every stop of the walk (k_collect_stops_prot), sorted by position on the device
+        const uint64_t nsamp_p = (h.n + h.sample_rate - 1) / h.sample_rate, total = nsamp_p + h.prot.end_marker_n;
+        uint64_t *d_pos = (uint64_t *)talloc(total * 8), *d_val = (uint64_t *)talloc(total * 8);
+        uint64_t *d_pos2 = (uint64_t *)talloc(total * 8), *d_val2 = (uint64_t *)talloc(total * 8);
+        k_collect_stops_prot<<<(unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, nsamp_p, d_pos, d_val);
+        HIP_CHECK(hipGetLastError());
+        size_t sort_bytes = 0;
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, d_pos, d_pos2, d_val, d_val2, (int)total, 0, 64, stream_));
+        void *d_sort = talloc(sort_bytes);
+        HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(d_sort, sort_bytes, d_pos, d_pos2, d_val, d_val2, (int)total, 0, 64, stream_));
+        std::vector<uint64_t> hp(total), hv(total);
+        HIP_CHECK(hipMemcpyAsync(hp.data(), d_pos2, total * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipMemcpyAsync(hv.data(), d_val2, total * 8, hipMemcpyDeviceToHost, stream_));
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        if (total >= (1ull << 31)) throw HipError{"protein index too large for the stop sort", -5};
+        if (hp.empty() || hp[0] != 0) bp.emplace_back(0, h.adjusted_sa0);       // (position 0 is the row firstISA: listed when that row is a sampled one)
+        for (uint64_t k = 0; k < total && hp[k] != ~0ull; ++k) bp.emplace_back(hp[k], hv[k]);
+      } else {
+      std::vector<uint64_t> brk_rows = h.selected_rows, brk_vals = h.selected_vals;
       const uint64_t nsel = brk_rows.size();
       std::vector<uint64_t> bpos(nsel + 1, 0);
       if (nsel) {
@@ -490,9 +498,9 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
         HIP_CHECK(hipMemcpyAsync(bpos.data() + 1, d_p, nsel * 8, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
       }
-      std::vector<std::pair<uint64_t, uint64_t>> bp;
       bp.emplace_back(0, h.adjusted_sa0);
       for (uint64_t g = 0; g < nsel; ++g) if (brk_rows[g] != h.first_isa) bp.emplace_back(bpos[g + 1], brk_vals[g]);
+      }
       std::sort(bp.begin(), bp.end());
       std::vector<uint64_t> spos, sval;
       for (const auto &e : bp) if (spos.empty() || e.second != sval.back()) { spos.push_back(e.first); sval.push_back(e.second); }
