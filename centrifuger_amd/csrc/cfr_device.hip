@@ -865,13 +865,16 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
   HIP_CHECK(hipEventRecord(ev_[1], stream_));
   // the six translations of every read of the sub-batch, once (k_translate_prot), then the searches read plain codes
-  uint8_t *codes1 = (uint8_t *)scratch(S_PCODES1, 2 * prot_total1_ + 64), *codes2 = paired ? (uint8_t *)scratch(S_PCODES2, 2 * prot_total2_ + 64) : nullptr;
+  // (regions are addressed by the read's byte offset and its number in the batch: prot_code_base)
+  const uint64_t read0 = prot_o1_base_ ? (uint64_t)(d_o1 - prot_o1_base_) : 0;
+  uint8_t *codes1 = (uint8_t *)scratch(S_PCODES1, 2 * prot_total1_ + 56 * (prot_reads_ + 1) + 128);
+  uint8_t *codes2 = paired ? (uint8_t *)scratch(S_PCODES2, 2 * prot_total2_ + 56 * (prot_reads_ + 1) + 128) : nullptr;
   if (paired) {
-    k_translate_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2);
-    k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2);
+    k_translate_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2, read0);
+    k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
   } else {
-    k_translate_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr);
-    k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr);
+    k_translate_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr, read0);
+    k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
@@ -1065,7 +1068,7 @@ void DeviceIndex::run_batch(const uint8_t *d_b1, const uint64_t *d_o1, const uin
   out.read_len.assign(n, 0);
   last_stats = cfr_batch_stats{};
   if (n == 0) return;
-  prot_total1_ = total1; prot_total2_ = total2;
+  prot_total1_ = total1; prot_total2_ = total2; prot_o1_base_ = d_o1; prot_reads_ = n;
   Pipe p;
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2);
   run_device_stages(d_b1, d_o1, d_b2, d_o2, n, total1, total2, want_rows, p, &out.hit_begin, false, /*row_space_only=*/true);   // the hits leave with real BWT rows
@@ -1132,7 +1135,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   last_stats = cfr_batch_stats{};
   if (match_extent) *match_extent = 0;
   if (n == 0) return;
-  prot_total1_ = total1; prot_total2_ = total2;
+  prot_total1_ = total1; prot_total2_ = total2; prot_o1_base_ = d_o1; prot_reads_ = n;
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
   if (stride && stride * n > match_cap) throw CapacityError{"match buffer too small"};

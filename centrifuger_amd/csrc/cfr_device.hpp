@@ -234,6 +234,8 @@ class DeviceIndex {
   int tail_blocks_per_cu_ = 0;           // blocks per CU of the post stage when it runs beside a search (0: one lane per read)
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {}, copied_[kMaxSub] = {};
   size_t sub_batch_ = 1250000, taper_floor_ = 262144;
+  const uint64_t *prot_o1_base_ = nullptr;      // offsets of the batch in flight (a sub-batch's read numbers are counted from here)
+  uint64_t prot_reads_ = 0;
   uint64_t prot_total1_ = 0, prot_total2_ = 0;  // bases of the whole batch in flight (the translated codes of a protein search are indexed by absolute offsets)
   uint64_t piece_bases_max_ = 12000000000ull;   // bases a sub-batch may hold (its raw hit lists must fit beside the image)
   int num_cus_ = 256, blocks_per_cu_ = 7;
