@@ -5,6 +5,8 @@
 #include <chrono>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -190,19 +192,34 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     // ---- run-block image: the 7 bitvectors as rank lines (cfr_device.hpp).  CFR_LAYOUT=rb searches on it directly;
     // otherwise it is only the source the flat occ image is expanded from (on the device) and is freed afterwards.
     std::vector<void *> rb_allocs;
+    // Small vectors: laid out in one host buffer and copied.  Large ones (a multi-Gbp index holds GBs of bitvector words) are
+    // streamed: slices of 64 k lines are counted by host threads (ones before every slice), then laid out - with their absolute
+    // counts - straight into two pinned staging buffers of 32 slices that travel to the device while the next ones are filled
+    // (one pass of pageable 14 GB through hipMemcpy cost 2.8 s of the 40 Gbp load).
+    struct Stage { uint64_t *p = nullptr; hipEvent_t done = nullptr; bool busy = false; };
+    Stage stage[2];
+    constexpr uint64_t kSliceLines = 1ull << 16, kChunkSlices = 32;                       // 4 MB slices, 128 MB per staging buffer
+    auto release_stages = [&]() {
+      for (auto &g : stage) { if (g.busy) (void)hipEventSynchronize(g.done); if (g.done) (void)hipEventDestroy(g.done); if (g.p) (void)hipHostFree(g.p); g = Stage{}; }
+    };
+    const unsigned host_threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    auto run_parallel = [&](uint64_t count, const std::function<void(uint64_t)> &fn) {
+      std::atomic<uint64_t> next{0};
+      const unsigned nt = (unsigned)std::min<uint64_t>(host_threads, count);
+      if (nt <= 1) { for (uint64_t k = 0; k < count; ++k) fn(k); return; }
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; ++t) th.emplace_back([&]() { for (;;) { const uint64_t k = next.fetch_add(1); if (k >= count) return; fn(k); } });
+      for (auto &x : th) x.join();
+    };
     auto lines_of = [&](const RawBitvector &bv) -> RankLines {
       const uint64_t nl = bv.n / 448 + 2;
-      std::vector<uint64_t> L(nl * 8, 0);
       // payload word wq of line k = bits [448k + 64wq, +64) of the vector (unaligned gather from the 64-bit words); the line's
-      // first word = ones before the line.  Parts of the vector are laid out by host threads (12 GB of bitvectors at 40 Gbp),
-      // each with counts relative to its own start; the parts' totals are added afterwards.
-      const unsigned parts = (unsigned)std::min<uint64_t>(std::max<uint64_t>(1, nl >> 16), std::min(32u, std::max(1u, std::thread::hardware_concurrency())));
-      std::vector<uint64_t> part_ones(parts + 1, 0);
-      auto fill = [&](unsigned t) {
-        const uint64_t lo = nl * t / parts, hi = nl * (t + 1) / parts;
-        uint64_t ones = 0;
+      // first word = ones before the line
+      auto fill_lines = [&](uint64_t lo, uint64_t hi, uint64_t ones, uint64_t *dst) -> uint64_t {      // lines [lo, hi) -> dst; returns the ones they hold
+        const uint64_t ones0 = ones;
         for (uint64_t k = lo; k < hi; ++k) {
-          L[k * 8] = ones;
+          uint64_t *L = dst + (k - lo) * 8;
+          L[0] = ones;
           for (int wq = 0; wq < 7; ++wq) {
             const uint64_t bit = k * 448 + (uint64_t)wq * 64;
             uint64_t w = 0;
@@ -212,30 +229,67 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
               if (sh && wi + 1 < bv.bits.size()) w |= bv.bits[wi + 1] << (64 - sh);
               if (bit + 64 > bv.n) w &= (1ull << (bv.n - bit)) - 1;      // nothing beyond the last bit
             }
-            L[k * 8 + 1 + wq] = w;
+            L[1 + wq] = w;
             ones += (uint64_t)__builtin_popcountll(w);
           }
         }
-        part_ones[t + 1] = ones;
+        return ones - ones0;
       };
-      if (parts == 1) fill(0);
-      else {
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < parts; ++t) th.emplace_back(fill, t);
-        for (auto &x : th) x.join();
-        for (unsigned t = 0; t < parts; ++t) part_ones[t + 1] += part_ones[t];
-        th.clear();
-        for (unsigned t = 1; t < parts; ++t) th.emplace_back([&, t]() {
-          const uint64_t lo = nl * t / parts, hi = nl * (t + 1) / parts, base = part_ones[t];
-          for (uint64_t k = lo; k < hi; ++k) L[k * 8] += base;
-        });
-        for (auto &x : th) x.join();
-      }
-      uint64_t *d = (uint64_t *)temp_alloc(L.size() * 8);
+      uint64_t *d = (uint64_t *)temp_alloc(nl * 64);
       rb_allocs.push_back(d);
-      HIP_CHECK(hipMemcpy(d, L.data(), L.size() * 8, hipMemcpyHostToDevice));
+      const uint64_t nslices = (nl + kSliceLines - 1) / kSliceLines;
+      if (nslices <= 1) {                                  // tiny: one buffer, one copy
+        std::vector<uint64_t> L(nl * 8);
+        fill_lines(0, nl, 0, L.data());
+        HIP_CHECK(hipMemcpy(d, L.data(), L.size() * 8, hipMemcpyHostToDevice));
+        return RankLines{d, bv.n};
+      }
+      // ones before every slice: popcount of the slice's bit range
+      std::vector<uint64_t> before(nslices + 1, 0);
+      run_parallel(nslices, [&](uint64_t sidx) {
+        const uint64_t from = std::min(bv.n, sidx * kSliceLines * 448), to = std::min(bv.n, (sidx + 1) * kSliceLines * 448);
+        uint64_t c = 0;
+        if (to > from) {
+          const uint64_t w0 = from >> 6, w1 = (to - 1) >> 6;
+          for (uint64_t w = w0; w <= w1; ++w) {
+            uint64_t x = bv.bits[w];
+            if (w == w0 && (from & 63)) x &= ~0ull << (from & 63);
+            if (w == w1 && ((to & 63) != 0)) x &= (1ull << (to & 63)) - 1;
+            c += (uint64_t)__builtin_popcountll(x);
+          }
+        }
+        before[sidx + 1] = c;
+      });
+      for (uint64_t k = 0; k < nslices; ++k) before[k + 1] += before[k];
+      if (nslices <= kChunkSlices) {                       // up to 128 MB: laid out by the threads, one copy
+        std::vector<uint64_t> L(nl * 8);
+        run_parallel(nslices, [&](uint64_t sidx) {
+          const uint64_t lo = sidx * kSliceLines, hi = std::min(nl, lo + kSliceLines);
+          fill_lines(lo, hi, before[sidx], L.data() + lo * 8);
+        });
+        HIP_CHECK(hipMemcpy(d, L.data(), L.size() * 8, hipMemcpyHostToDevice));
+        return RankLines{d, bv.n};
+      }
+      for (auto &g : stage) if (!g.p) {
+        HIP_CHECK(hipHostMalloc((void **)&g.p, kChunkSlices * kSliceLines * 64, hipHostMallocDefault));
+        HIP_CHECK(hipEventCreateWithFlags(&g.done, hipEventDisableTiming));
+      }
+      for (uint64_t c0 = 0, chunk = 0; c0 < nslices; c0 += kChunkSlices, ++chunk) {
+        Stage &g = stage[chunk & 1];
+        if (g.busy) { HIP_CHECK(hipEventSynchronize(g.done)); g.busy = false; }
+        const uint64_t c1 = std::min(nslices, c0 + kChunkSlices);
+        run_parallel(c1 - c0, [&](uint64_t j) {
+          const uint64_t sidx = c0 + j, lo = sidx * kSliceLines, hi = std::min(nl, lo + kSliceLines);
+          fill_lines(lo, hi, before[sidx], g.p + j * kSliceLines * 8);
+        });
+        const uint64_t lo = c0 * kSliceLines, hi = std::min(nl, c1 * kSliceLines);
+        HIP_CHECK(hipMemcpyAsync(d + lo * 8, g.p, (hi - lo) * 64, hipMemcpyHostToDevice, stream_));
+        HIP_CHECK(hipEventRecord(g.done, stream_));
+        g.busy = true;
+      }
       return RankLines{d, bv.n};
     };
+    struct StageGuard { std::function<void()> f; ~StageGuard() { f(); } } stage_guard{release_stages};
     view_.rb.use = lines_of(h.use_run_block);
     for (int k = 0; k < 3; ++k) {
       view_.rb.plain[k] = h.wavelet_seq.node_cnt ? lines_of(h.wavelet_seq.node[k]) : RankLines{nullptr, 0};
@@ -247,6 +301,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     view_.rb.b = h.b;
     view_.rb.block_cnt = h.block_cnt;
     view_.rb.filter_rate = (uint32_t)h.selected_filter_rate;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    release_stages();
     lap("rank lines (host) + upload");
     if (layout_rb) {
       for (void *q : rb_allocs) { temps_.erase(std::find(temps_.begin(), temps_.end(), q)); owned_.push_back(q); }
