@@ -105,8 +105,7 @@ void parse_bitvector(Cursor &c, RawBitvector &bv) {
   c.get<uint64_t>();                        // rank9 _space
   uint64_t word_cnt = c.get<uint64_t>();
   if (word_cnt != words) throw FormatError{"rank9 word count mismatch"};
-  bv.rank9.resize(2 * ceil_div(word_cnt, 8));
-  c.copy(bv.rank9.data(), bv.rank9.size() * 8);
+  c.skip(2 * ceil_div(word_cnt, 8) * 8);    // the rank9 blocks themselves: not used (rank lines are counted at image build)
   c.get<uint64_t>();                        // select _space
   uint64_t sel_n = c.get<uint64_t>();
   int32_t sel_speed = c.get<int32_t>();
@@ -200,7 +199,8 @@ void parse_fm(const std::string &path, HostIndex &h) {
   h.sampled_n = c.get<uint64_t>();
   if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
   uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
-  h.sampled_words.assign(sw + 2, 0);       // +2: device reads two words unconditionally
+  h.sampled_words.resize(sw + 2);          // +2: device reads two words unconditionally
+  h.sampled_words[sw] = h.sampled_words[sw + 1] = 0;
   c.copy(h.sampled_words.data(), sw * 8);
   h.ftab.resize(2 * h.precompute_size);
   c.copy(h.ftab.data(), h.ftab.size() * 8);
@@ -308,7 +308,8 @@ void parse_fm_protein(const std::string &path, HostIndex &h) {
   h.sampled_n = c.get<uint64_t>();
   if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
   const uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
-  h.sampled_words.assign(sw + 2, 0);
+  h.sampled_words.resize(sw + 2);
+  h.sampled_words[sw] = h.sampled_words[sw + 1] = 0;
   c.copy(h.sampled_words.data(), sw * 8);
   h.ftab.resize(2 * h.precompute_size);
   c.copy(h.ftab.data(), h.ftab.size() * 8);

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -17,10 +18,19 @@
 
 namespace cfr {
 
-struct RawBitvector {          // Bitvector_Plain + DS_Rank9 as stored
-  uint64_t n = 0;              // bits
-  std::vector<uint64_t> bits;  // ceil(n/64)
-  std::vector<uint64_t> rank9; // 2*ceil(words/8): abs count, 7x9-bit relative counts
+// words read straight from a file: a vector whose resize() does not zero-fill first (a 40 Gbp index holds 15 GB of them; the
+// fill was a single-threaded pass of its own in front of the copy)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  template <class U, class... A> void construct(U *p, A &&...a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+using RawWords = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
+
+struct RawBitvector {          // Bitvector_Plain as stored (its DS_Rank9 blocks are checked for size and skipped: the device image
+  uint64_t n = 0;              // bits                             counts its own rank lines)
+  RawWords bits;               // ceil(n/64)
 };
 
 struct RawWavelet {            // Sequence_WaveletTree<Bitvector_Plain> for sigma=4: 3 nodes
@@ -71,7 +81,7 @@ struct HostIndex {
   uint64_t sample_size = 0, precompute_width = 0, precompute_size = 0, adjusted_sa0 = 0;
   int32_t sampled_bits = 0;
   uint64_t sampled_n = 0;
-  std::vector<uint64_t> sampled_words;
+  RawWords sampled_words;
   std::vector<uint64_t> ftab;           // pairs (start, count)
   int32_t selected_filter_rate = 1024;
   std::vector<uint64_t> selected_rows, selected_vals;   // ascending rows

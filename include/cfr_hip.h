@@ -151,9 +151,10 @@ cfr_status cfr_backward_search_batch(cfr_dev_index *d, const uint8_t *bases, con
 cfr_status cfr_locate_rows(cfr_dev_index *d, const uint64_t *rows, size_t n, uint64_t *out_val, uint32_t *out_steps);
 
 /* Self-check of the tables the device image derives at load time, against the BWT itself (no reference counterpart: the
- * reference has no derived tables).  out[0..3] = number of rows where SA/ISA, the 2-bit text, the LF order of SA, the locate
- * memo (every 61st row, against the plain FMIndex::BackwardToSampledSA walk) disagree - all 0 on a sound image;
- * out[4] = 1 if the text-mode tables exist, out[5] = 0 without a locate memo, else 1 + log2 of its row rate. */
+ * reference has no derived tables).  out[0..3] = number of rows where the suffix array (SA[i] < n, 0 exactly at the row of text
+ * position 0), the text (symbol left of SA[i] = B[i]), the LF order (SA[LF(i)] = SA[i] - 1) and the direct locate (memo, or
+ * suffix array + step function; every 61st row, against the plain FMIndex::BackwardToSampledSA walk) disagree - all 0 on a sound
+ * image; out[4] = 1 if the text-mode tables exist, out[5] = 0 without a locate memo, else 1 + log2 of its row rate. */
 cfr_status cfr_selfcheck_tables(cfr_dev_index *d, uint64_t out[6]);
 
 /* ---- the path ---- */
