@@ -673,7 +673,6 @@ void DeviceIndex::release() {            // idempotent: also the clean-up of a c
   slots_.clear();
   if (pinned_) (void)hipHostFree(pinned_);
   pinned_ = nullptr; pinned_cap_ = 0;
-  link_.reset();
   auto drop_event = [](hipEvent_t &e) { if (e) (void)hipEventDestroy(e); e = nullptr; };
   for (auto &set : evs_) for (auto &e : set) drop_event(e);
   for (auto &e : tail_done_) drop_event(e);
@@ -1244,11 +1243,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     for (size_t k = 0; k < nsub; ++k) { m1 = std::max(m1, b1[k + 1] - b1[k]); if (paired) m2 = std::max(m2, b2[k + 1] - b2[k]); }
     for (size_t k = 0; k < nsub; ++k) { pt1[k] = m1; pt2[k] = m2; }
   }
-  // pageable caller buffers go through the library's own pinned chunks (cfr_hostlink.hpp); CFR_HOST_LINK=0: the runtime's staging
-  static const bool link_on = !(dbg_env("CFR_HOST_LINK") && atoi(dbg_env("CFR_HOST_LINK")) == 0);
-  if (link_) link_->reset();                              // (chunks a failed call left pending)
-  const bool up1 = src && link_on && HostLink::pageable(src->b1), up2 = src && link_on && paired && HostLink::pageable(src->b2);
-  const bool down_res = link_on && HostLink::pageable(results), down_match = link_on && stride && HostLink::pageable(matches);
   const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
@@ -1265,14 +1259,12 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       have_piece[k] = 1;
       return;
     }
-    auto one = [&](const uint8_t *hb, const uint64_t *ho, const uint8_t *db, bool staged) {
+    auto one = [&](const uint8_t *hb, const uint64_t *ho, const uint8_t *db) {
       const uint64_t a = ho[lo], b = ho[hi];
-      if (b <= a) return;
-      if (staged) HIP_CHECK(link().h2d(const_cast<uint8_t *>(db) + a, hb + a, b - a, h2d_stream_));
-      else HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
+      if (b > a) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
     };
-    one(src->b1, src->o1, d_b1, up1);
-    if (paired) one(src->b2, src->o2, d_b2, up2);
+    one(src->b1, src->o1, d_b1);
+    if (paired) one(src->b2, src->o2, d_b2);
     if (dust_ && !view_.prot.enabled) {
       // masked on a stream of its own, behind the piece's copy: the copy stream goes straight on with the next piece (the link
       // is what bounds this entry: 187 MB per piece at ~47 GB/s = 4 ms, the mask kernel 1.1-1.4 ms - on the copy stream
@@ -1334,10 +1326,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipStreamWaitEvent(copy_stream_, tail_done_[par], 0));
     static const bool no_copy = dbg_env("CFR_NO_COPY_OUT") && atoi(dbg_env("CFR_NO_COPY_OUT"));     // diagnosis: the step without its D2H
     if (!no_copy) {
-      if (down_res) HIP_CHECK(link().d2h(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, copy_stream_));
-      else HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, hipMemcpyDeviceToHost, copy_stream_));
-      if (extent && down_match && stride) HIP_CHECK(link().d2h(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, copy_stream_));
-      else if (extent) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, hipMemcpyDeviceToHost, copy_stream_));
+      HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, hipMemcpyDeviceToHost, copy_stream_));
+      if (extent) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, hipMemcpyDeviceToHost, copy_stream_));
     }
     if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
     if (d_heavy) HIP_CHECK(hipMemcpyAsync(h_heavy, d_heavy, 8, hipMemcpyDeviceToHost, copy_stream_));
@@ -1404,9 +1394,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k], ts, heavy ? ctl + 2 : nullptr, &heavy_h[k]);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
-        if (link_ && (down_res || down_match)) HIP_CHECK(link_->drain(false));   // results whose chunks have landed
       }
-      if (link_ && (down_res || down_match)) HIP_CHECK(link_->drain(true));
       HIP_CHECK(hipStreamSynchronize(stream_));
       HIP_CHECK(hipStreamSynchronize(tail_stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
@@ -1447,7 +1435,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipGetLastError());
     copy_out(k, d_res, d_match, extent, nullptr, nullptr, stream_);
   }
-  if (link_ && (down_res || down_match)) HIP_CHECK(link_->drain(true));
   HIP_CHECK(hipStreamSynchronize(stream_));
   HIP_CHECK(hipStreamSynchronize(copy_stream_));
   if (!one_launch) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
@@ -1483,33 +1470,19 @@ void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uin
     uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
     // the offsets travel on the same stream as the bases: the SDUST kernel of a piece runs there and reads them, and the
     // main stream only touches a piece behind that stream's event
-    static const bool link_on = !(dbg_env("CFR_HOST_LINK") && atoi(dbg_env("CFR_HOST_LINK")) == 0);
-    auto offsets_up = [&](uint64_t *d, const uint64_t *h) {
-      if (link_on && HostLink::pageable(h)) HIP_CHECK(link().h2d(d, h, (n + 1) * 8, h2d_stream_));
-      else HIP_CHECK(hipMemcpyAsync(d, h, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
-    };
-    offsets_up(d_o1, o1);
+    HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
     uint8_t *d_b2 = nullptr;
     uint64_t *d_o2 = nullptr;
     if (b2) {
       d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 16);
       d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
-      offsets_up(d_o2, o2);
+      HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
     }
     classify_device(d_b1, d_o1, d_b2, d_o2, n, t1, t2, results, matches, match_cap, match_extent, &src);
     return;
   }
   Staged st = stage_inputs(b1, o1, b2, o2, n);
   classify_device(st.b1, st.o1, st.b2, st.o2, n, st.t1, st.t2, results, matches, match_cap, match_extent);
-}
-
-HostLink &DeviceIndex::link() {
-  if (!link_) {
-    int threads = 8;
-    if (const char *e = dbg_env("CFR_LINK_THREADS")) threads = std::max(1, std::min(64, atoi(e)));
-    link_.reset(new HostLink(threads));
-  }
-  return *link_;
 }
 
 void *DeviceIndex::pinned(size_t bytes) {

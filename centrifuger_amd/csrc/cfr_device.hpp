@@ -31,12 +31,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
 
-#include "cfr_hostlink.hpp"
 #include "cfr_index.hpp"
 
 namespace cfr {
@@ -248,8 +246,6 @@ class DeviceIndex {
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
-  std::unique_ptr<HostLink> link_;     // staging of pageable caller buffers (made at the first such call)
-  HostLink &link();
 };
 
 }  // namespace cfr
