@@ -421,7 +421,7 @@ def test_bounded_dust_equals_the_literal_scan():
 
 def test_bench_gpus_flag_is_honoured():
     """`bench.py --gpus N` must mean N ranks: a launcher that started a different WORLD_SIZE is an error, and without a
-    launcher the script starts the ranks itself (here every rank then stops at "needs an MI355X": there is no CPU path)."""
+    launcher the script starts the ranks itself (here the ranks then stop at "needs an MI355X": there is no CPU path)."""
     import subprocess
     import sys
     bench = os.path.join(ROOT, "bench.py")
@@ -434,7 +434,8 @@ def test_bench_gpus_flag_is_honoured():
     assert b"spawning 2 ranks" in r.stderr
     import torch
     if not torch.cuda.is_available():
-        assert r.returncode != 0 and r.stderr.count(b"needs an MI355X") >= 2
+        # (the launcher stops the other rank as soon as the first one has failed: one message is certain, two are usual)
+        assert r.returncode != 0 and r.stderr.count(b"needs an MI355X") >= 1
 
 
 def test_host_dust_twins_and_oracle_equal_the_reference_dumps():
