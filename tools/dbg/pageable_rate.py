@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """cfr_classify_batch from PAGEABLE host buffers that are allocated once and touched (what a caller that recycles its batch
 buffers hands over): reads/s, single-end -k 1 and pairs -k 5, with and without the SDUST pre-step.
-Measured (r3r): 3.0e8 reads/s, the same as from cfr_host_alloc memory - the runtime pins such buffers in place.  A staging
-layer of the library's own (pinned chunks filled by a crew of copy threads) was tried against it and changed nothing; the
-8.7e7 that earlier bench lines reported for "pageable" was the page faults of freshly allocated result arrays.
+Measured (r3r, two boxes): 1.8e8 and 3.0e8 reads/s pageable, 3.3e8 pinned.  A staging layer of the library's own (pinned
+chunks filled by a crew of copy threads) was tried against the runtime's and changed nothing; the 8.7e7 that earlier bench
+lines reported for "pageable" was the page faults of freshly allocated result arrays.  HL_PIN=1 (set by the driver mode for
+its "pinned" legs) runs the same calls from cfr_host_alloc memory; CFR_DUST_INLINE was an experiment that is no longer in the library.
 Usage: python tools/dbg/pageable_rate.py [reads]"""
 import os, sys, time, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -34,10 +35,20 @@ def child(reads, pairs):
         b2 = None
     b1 = r1.reshape(-1).cpu().numpy().copy()
     offs = (np.arange(reads + 1, dtype=np.uint64) * 150)
+    if os.environ.get("HL_PIN"):                      # the same legs from cfr_host_alloc memory
+        keep = []
+        def pin(a):
+            pa = capi.PinnedArray(a.size, a.dtype); pa.array[:] = a; keep.append(pa); return pa.array
+        b1 = pin(b1); offs = pin(offs)
+        if b2 is not None: b2 = pin(b2)
     idx = capi.Index(prefix, capi.default_params(max_result=k))
     dev = capi.DeviceIndex(idx, 0)
-    results = np.empty(reads, dtype=capi.RESULT_DTYPE); results.view(np.uint8)[:] = 0            # touched: no page faults in the timed calls
-    matches = np.empty(reads * k, dtype=capi.MATCH_DTYPE); matches.view(np.uint8)[:] = 0
+    if os.environ.get("HL_PIN"):
+        pr, pm = capi.PinnedArray(reads, capi.RESULT_DTYPE), capi.PinnedArray(reads * k, capi.MATCH_DTYPE)
+        results, matches = pr.array, pm.array
+    else:
+        results = np.empty(reads, dtype=capi.RESULT_DTYPE); results.view(np.uint8)[:] = 0            # touched: no page faults in the timed calls
+        matches = np.empty(reads * k, dtype=capi.MATCH_DTYPE); matches.view(np.uint8)[:] = 0
     out = {}
     for dust in (False, True):
         dev.set_dust(dust)
@@ -59,7 +70,7 @@ if __name__ == "__main__":
         sys.exit(0)
     reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     for mode in ("se", "pe"):
-        for name, env in [("pageable", {})]:
+        for name, env in [("pageable", {}), ("pinned", {"HL_PIN": "1"})]:
             e = dict(os.environ, HL_CHILD="1", **env)
             p = subprocess.run([sys.executable, os.path.abspath(__file__), str(reads if mode == "se" else reads // 2), mode], env=e, capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
