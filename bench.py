@@ -303,6 +303,46 @@ def live_pmc(args, cache, gpu=0):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def live_pmc_protein(args, n):
+    """The protein leg's counters, measured like live_pmc: this script re-executed (--mode protein --inner) under rocprofv3 --pmc, one
+    pass per counter group, k_search_prot and k_translate_prot.  Returns {kernel: {counter: value, "ms": duration}} or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    inner = [sys.executable, os.path.abspath(__file__), "--mode", "protein", "--inner", "--reads", str(n), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--prot-species", str(args.prot_species), "--seed", str(args.seed), "--cache", args.cache] + (["-k", str(args.k)] if args.k is not None else [])
+    env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")      # the step as ONE launch of each kernel
+    out = {}
+    work = tempfile.mkdtemp(prefix="cfr_pmc_", dir="/tmp")
+    try:
+        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE"])):
+            d = os.path.join(work, f"pass{gi}")
+            r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "k_search_prot|k_translate_prot",
+                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != 0:
+                log("live PMC pass (protein) failed:", r.stderr.decode()[-400:])
+                return None
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    for kname in ("k_search_prot", "k_translate_prot"):
+                        if kname in row["Kernel_Name"]:
+                            e = out.setdefault(kname, {})
+                            e[row["Counter_Name"]] = float(row["Counter_Value"])        # last dispatch = the timed step
+                            e["ms"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        if "TCC_EA0_RDREQ_sum" not in out.get("k_search_prot", {}) or "WRITE_SIZE" not in out.get("k_search_prot", {}):
+            return None
+        return out
+    except Exception as e:
+        log("live PMC (protein) unavailable:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def cache_key(args):
     return hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")
                         + ("-fastgen" if args.index_gbp else "")).encode()).hexdigest()[:10]
@@ -528,6 +568,34 @@ def protein_mode(torch, capi, args, device):
                                   f"centrifuger-build --protein), {n} x 150 bp DNA reads per step, -k {k}, inputs resident in HBM", "index_symbols": int(info.n)},
            "classified_fraction": float((results["n_match"] > 0).mean()),
            "stage_ms": {kk: float(np.mean([getattr(s_, kk) for s_ in kst])) for kk in ("search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")}}
+    if getattr(args, "inner", False):
+        print(json.dumps(out), flush=True)
+        dev.close()
+        return
+    if not args.no_pmc:
+        dev.close()                          # the child builds the same image on the same GPU
+        pm = live_pmc_protein(args, n)
+        dev = capi.DeviceIndex(idx, device.index or 0)
+        if pm:
+            # k_search_prot is the dominant kernel: dependent gathers into the K-mer table, the 128-byte occurrence records, the
+            # suffix array and the byte text - HBM / fabric bound like the nucleotide search (a request = one 128-byte line,
+            # profiles/r2a_gather_calib.json).  Its duration: the kernel trace of the counter pass (the in-library events
+            # bracket caps + scan + translate + search together: stage_ms.search_ms).
+            sp, tp = pm["k_search_prot"], pm.get("k_translate_prot", {})
+            rd, wr = sp["TCC_EA0_RDREQ_sum"] * 128.0, sp["WRITE_SIZE"] * 1024.0
+            out["roofline"] = {"bound": "hbm", "kernel": "k_search_prot", "peak": 8000.0, "unit": "GB/s", "kernel_ms": sp["ms"],
+                               "achieved": (rd + wr) / (sp["ms"] * 1e-3) / 1e9, "frac": (rd + wr) / (sp["ms"] * 1e-3) / 1e9 / 8000.0, "traffic": rd + wr,
+                               "fabric_read_requests_per_read": sp["TCC_EA0_RDREQ_sum"] / n, "read_bytes_per_read": rd / n, "write_bytes_per_read": wr / n,
+                               "requests_per_s": sp["TCC_EA0_RDREQ_sum"] / (sp["ms"] * 1e-3),
+                               "gather_ceiling_frac": sp["TCC_EA0_RDREQ_sum"] / (sp["ms"] * 1e-3) / 48e9,
+                               "translate_kernel": {"kernel": "k_translate_prot", "ms": tp.get("ms"),
+                                                    "read_bytes": tp.get("TCC_EA0_RDREQ_sum", 0.0) * 128.0, "write_bytes": tp.get("WRITE_SIZE", 0.0) * 1024.0},
+                               "traffic_source": f"live in this run: rocprofv3 --pmc (2 passes, --kernel-trace) around one {n}-read step of the same build; "
+                                                 "kernel_ms is that trace's duration of the kernel",
+                               "note": "achieved = (TCC_EA0_RDREQ x 128 B + WRITE_SIZE) of k_search_prot / its duration; 6 chains per read (strand x frame), one lane each"}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "k_search_prot", "peak": 8000.0, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+                               "note": "rocprofv3 --pmc not usable here"}
     refbin = os.path.join(ref_dir, "centrifuger")
     if not args.no_cpu_baseline and os.path.exists(refbin):
         nb = min(args.cpu_sample if args.cpu_sample != 2_000_000 else 400_000, n)

@@ -925,11 +925,12 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   const uint64_t read0 = prot_o1_base_ ? (uint64_t)(d_o1 - prot_o1_base_) : 0;
   uint8_t *codes1 = (uint8_t *)scratch(S_PCODES1, 2 * prot_total1_ + 56 * (prot_reads_ + 1) + 128);
   uint8_t *codes2 = paired ? (uint8_t *)scratch(S_PCODES2, 2 * prot_total2_ + 56 * (prot_reads_ + 1) + 128) : nullptr;
+  const unsigned tr_grid = std::min<unsigned>((unsigned)((n * (paired ? 2 : 1) + 3) / 4), (unsigned)(num_cus_ * 8));   // a wave per read and mate, grid-stride
   if (paired) {
-    k_translate_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2, read0);
+    k_translate_prot<2><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2, read0);
     k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
   } else {
-    k_translate_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr, read0);
+    k_translate_prot<1><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr, read0);
     k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
   }
   HIP_CHECK(hipGetLastError());
