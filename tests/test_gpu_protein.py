@@ -119,3 +119,47 @@ def test_protein_hits_equal_oracle(prot_dir):
         for f in ("sp", "ep", "l", "strand", "offset"):
             assert np.array_equal(got[f], want[f]), (ids[i], f)
     dev.close()
+
+
+def test_translation_of_odd_reads_equals_oracle(prot_dir):
+    """k_translate_prot's two forms (reads staged in LDS up to 1024 characters, longer ones straight from memory) on reads of awkward
+    lengths and characters - empty, 1-5 bases, around the staging limit, several thousand bases, lower case, N, IUPAC letters -
+    through the hit lists of the translated search against the C oracle (DnaToAa's ladder decides what an odd character becomes)."""
+    prefix = os.path.join(prot_dir, "p3_b4")
+    idx = capi.Index(prefix, capi.default_params(max_result=3))
+    dev = capi.DeviceIndex(idx)
+    o = ora.OracleIndex(prefix, max_result=3)
+    _, b, offs = ora.read_fastx(os.path.join(prot_dir, "se.fa"))
+    base = [bytes(b[int(offs[i]):int(offs[i + 1])]) for i in range(min(40, len(offs) - 1))]
+    rng = np.random.default_rng(11)
+    reads = [b"", b"A", b"AC", b"ACG", b"ACGT", b"ACGTA", b"N" * 70, b"acgt" * 30]
+    joined = b"".join(base)
+    for L in (149, 150, 151, 1022, 1023, 1024, 1025, 1026, 3000, len(joined)):
+        reads.append(joined[:L])
+        reads.append(joined[7:7 + L])
+    for r in base[:12]:
+        a = bytearray(r)
+        for ch in (b"N", b"n", b"R", b"a", b"t", b"-"):
+            a[int(rng.integers(0, len(a)))] = ch[0]
+        reads.append(bytes(a))
+    long_odd = bytearray(joined[:2500])
+    for p in rng.integers(0, len(long_odd), size=40):
+        long_odd[int(p)] = b"NnRYacgt"[int(rng.integers(0, 8))]
+    reads.append(bytes(long_odd))
+    o1 = np.zeros(len(reads) + 1, dtype=np.uint64)
+    o1[1:] = np.cumsum([len(r) for r in reads])
+    b1 = np.frombuffer(b"".join(reads), dtype=np.uint8).copy()
+    hits, hb = dev.search(b1, o1)
+    for i, r in enumerate(reads):
+        want = o.query_hits(r)
+        got = hits[int(hb[i]):int(hb[i + 1])]
+        assert len(got) == len(want), (i, len(r))
+        for f in ("sp", "ep", "l", "strand", "offset"):
+            assert np.array_equal(got[f], want[f]), (i, len(r), f)
+    # and the classification itself (text mode, hits in text-position space): the TSV lines against the oracle's
+    res, mat = dev.classify(b1, o1)
+    ids = [f"r{i}" for i in range(len(reads))]
+    want_tsv = o.tsv(ids, o.classify(b1, o1))
+    got_tsv = capi.tsv_header() + b"".join(idx.format_tsv(ids[i], res[i], mat) for i in range(len(reads)))
+    assert got_tsv == want_tsv
+    dev.close()
