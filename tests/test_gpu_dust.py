@@ -208,3 +208,48 @@ def test_one_instantiation_for_all_reads():
     tail = r.stdout.decode()[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in tail
+
+
+def test_reads_with_one_non_symbol_go_through_the_64_triplet_kernel(dev):
+    """A read with exactly ONE character that is not A, C, G or T is scanned by the 64-triplet instantiation with that character's
+    three triplets as uncounted placeholders (k_dust, cfr_kernels.hip.inc); two or more take the 125-triplet one.  20 000 reads of
+    repeats and random stretches with one such character (N, n, X, a lower-case base) at any place - first, second, third, last
+    base included - and 2 000 with two, against the literal host twin (which is pinned to the reference's own dumps)."""
+    idx, d = dev
+    rng = np.random.default_rng(1234)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    odd = np.frombuffer(b"NnXacgt-", dtype=np.uint8)
+    out = []
+    for i in range(22000):
+        L = int(rng.integers(1, 320))
+        parts, have = [], 0
+        while have < L:
+            k = int(rng.integers(1, 90))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                p = np.full(k, acgt[rng.integers(0, 4)], dtype=np.uint8)
+            elif kind == 1:
+                p = np.resize(acgt[rng.integers(0, 4, size=int(rng.integers(2, 6)))], k)
+            else:
+                p = acgt[rng.integers(0, 4, size=k)]
+            parts.append(p)
+            have += k
+        r = np.concatenate(parts)[:L].copy()
+        for _ in range(1 if i < 20000 else 2):
+            r[int(rng.integers(0, L))] = odd[rng.integers(0, len(odd))]
+        out.append(r)
+    for pos in (0, 1, 2, 3, 60, 61, 62, 63, 64, 65, 147, 148, 149):       # the places the window logic cares about, on a poly-A read
+        r = np.full(150, ord("A"), dtype=np.uint8)
+        r[pos] = ord("N")
+        out.append(r)
+    b = np.concatenate(out)
+    o = np.concatenate([[0], np.cumsum([len(r) for r in out])]).astype(np.uint64)
+    host = b.copy()
+    capi.dust_mask(host, o, threads=8, literal=True)
+    for shift in (0, 3):
+        buf = np.concatenate([np.full(shift, ord("G"), dtype=np.uint8), b])
+        oo = np.concatenate([[0], o + np.uint64(shift)]).astype(np.uint64)
+        got = buf.copy()
+        d.dust_mask(got, oo)
+        assert np.array_equal(got[shift:], host), shift
+    assert (host != b).sum() > 100000          # (the set does get masked)
