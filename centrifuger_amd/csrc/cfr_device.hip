@@ -37,7 +37,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -828,9 +828,14 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   const bool text_hits = !search_v1_ && !row_space_only && have_sa() && view_.steps.pos && view_.text2;
 
   HIP_CHECK(hipEventRecord(ev_[0], stream_));
-  HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
-  k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
-  exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
+  if (pre_hit_off_) {                    // the offsets exist (one pass over the whole batch): the sub-batch's lists start at pre_hit_base_
+    hit_off = const_cast<uint64_t *>(pre_hit_off_);
+    raw = reinterpret_cast<cfr_hit *>(reinterpret_cast<uintptr_t>(raw) - (uintptr_t)pre_hit_base_ * sizeof(cfr_hit));
+  } else {
+    HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
+    k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
+    exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
+  }
   HIP_CHECK(hipEventRecord(ev_[1], stream_));
   if (search_v1_) {
     if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
@@ -1190,6 +1195,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
                                   size_t *match_extent, const HostSrc *src, bool compact) {
   HIP_CHECK(hipSetDevice(device_));
   last_stats = cfr_batch_stats{};
+  pre_hit_off_ = nullptr;
   if (match_extent) *match_extent = 0;
   if (n == 0) return;
   prot_total1_ = total1; prot_total2_ = total2; prot_o1_base_ = d_o1; prot_reads_ = n;
@@ -1229,6 +1235,22 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // bases of every piece (its buffers are sized by them): from the caller's offsets, or 8 bytes per boundary from the device
   std::vector<uint64_t> pt1(nsub, total1), pt2(nsub, total2);
   std::vector<uint64_t> b1(nsub + 1, 0), b2(nsub + 1, 0);          // byte offsets of the pieces' first reads (and of the end)
+  // resident reads in several sub-batches: the hit-list offsets of all reads in one pass (k_caps + scan per sub-batch were 12 small
+  // launches in front of 12 searches: 0.33 ms of a 14.4 ms step), the sub-batches' first offsets fetched with their boundaries
+  static const bool caps_once_on = !(dbg_env("CFR_CAPS_ONCE") && atoi(dbg_env("CFR_CAPS_ONCE")) == 0);
+  const bool caps_once = caps_once_on && !src && !dust_pieces && nsub > 1 && stride > 0 && one_launch_ready() && !search_v1_;
+  uint64_t *hit_all = nullptr;
+  std::vector<uint64_t> hbase(nsub + 1, 0);
+  if (caps_once) {
+    uint64_t *cap_all = (uint64_t *)scratch(S_CAPALL, (n + 1) * 8);
+    hit_all = (uint64_t *)scratch(S_HITALL, (n + 1) * 8);
+    size_t tb = scan_tmp_bytes(n);
+    void *tmp = scratch(S_SCANALL, tb);
+    HIP_CHECK(hipMemsetAsync(cap_all + n, 0, 8, stream_));
+    k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap_all);
+    exclusive_scan(tmp, tb, cap_all, hit_all, n, stream_);
+    for (size_t k = 0; k < nsub; ++k) HIP_CHECK(hipMemcpyAsync(&hbase[k], hit_all + pieces[k].first, 8, hipMemcpyDeviceToHost, stream_));
+  }
   if (nsub > 1 || by_piece) {
     for (size_t k = 0; k <= nsub; ++k) {
       const size_t at = k < nsub ? pieces[k].first : n;
@@ -1365,7 +1387,10 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const int par = tail_overlap ? (int)(k & 1) : 0;
         hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
         if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
+        pre_hit_off_ = hit_all ? hit_all + lo : nullptr;
+        pre_hit_base_ = hit_all ? hbase[k] : 0;
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], par);
+        pre_hit_off_ = nullptr;
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
         if (tail_overlap) {
           HIP_CHECK(hipEventRecord(search_done_[par], stream_));

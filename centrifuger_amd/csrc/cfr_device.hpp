@@ -246,6 +246,8 @@ class DeviceIndex {
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)
   void *pinned_ = nullptr;
   size_t pinned_cap_ = 0;
+  const uint64_t *pre_hit_off_ = nullptr;   // launch_search: hit-list offsets of the sub-batch's reads computed for the whole batch already
+  uint64_t pre_hit_base_ = 0;              //   (classify_device), and the offset of its first read (the raw buffer is the sub-batch's)
 };
 
 }  // namespace cfr
