@@ -53,6 +53,8 @@ VARIANTS = {
     "post_stage_overlapped_many_subbatches": {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0"},
     "post_stage_overlapped_grid_stride": {"CFR_TAIL_STREAM": "1", "CFR_TAIL_BLOCKS": "1", "CFR_SUBBATCH": "1000", "CFR_TAPER_FLOOR": "0"},
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
+    # hit-list offsets per sub-batch (k_caps + scan in front of every search) instead of one pass over the resident batch
+    "hit_offsets_per_sub_batch": {"CFR_CAPS_ONCE": "0", "CFR_SUBBATCH": "43", "CFR_TAPER_FLOOR": "0"},
 }
 
 
