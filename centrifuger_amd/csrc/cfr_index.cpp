@@ -338,7 +338,11 @@ void parse_fm_protein(const std::string &path, HostIndex &h) {
     uint64_t code = 0;
     int depth = 0;
     while (ti != -1) {
-      if (ti < 0 || (size_t)ti >= comp.node.size() || cur[(size_t)ti] >= comp.node[(size_t)ti].n || ++depth > 16) throw FormatError{"wavelet tree walk left the tree"};
+      if (ti < 0 || (size_t)ti >= comp.node.size() || cur[(size_t)ti] >= comp.node[(size_t)ti].n || ++depth > 16)
+        throw FormatError{"wavelet tree walk left the tree (node " + std::to_string(ti) + " of " + std::to_string(comp.node.size()) + ", bit " +
+                          std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? cur[(size_t)ti] : 0) + " of " +
+                          std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? comp.node[(size_t)ti].n : 0) + ", depth " + std::to_string(depth) +
+                          ", symbol " + std::to_string(produced) + " of " + std::to_string(comp.n) + ", n " + std::to_string(h.n) + ")"};
       const unsigned bit = bit_at(comp.node[(size_t)ti], cur[(size_t)ti]++);
       code = (code << 1) | bit;
       ti = bit ? comp.child1[(size_t)ti] : comp.child0[(size_t)ti];
