@@ -90,7 +90,7 @@ EXPORTS = [
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
-    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads",
+    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest",
 ]
 
 _lib = None
@@ -211,6 +211,12 @@ class Index:
         info = IndexInfo()
         _check(lib().cfr_index_get_info(self._h, C.byref(info)))
         return info
+
+    def digest(self) -> int:
+        """cfr_index_digest: 64-bit digest of everything the parser produced"""
+        d = C.c_uint64(0)
+        _check(lib().cfr_index_digest(self._h, C.byref(d)))
+        return d.value
 
     def close(self):
         if self._h:

@@ -126,6 +126,12 @@ cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info) {
   return CFR_OK;
 }
 
+cfr_status cfr_index_digest(const cfr_index *idx, uint64_t *digest) {
+  if (!idx || !digest) return bad_arg("cfr_index_digest: null argument");
+  *digest = cfr::index_digest(*idx->h);
+  return CFR_OK;
+}
+
 cfr_status cfr_device_count(int *count) {
   if (!count) return bad_arg("cfr_device_count: null argument");
   int c = 0;

@@ -58,6 +58,11 @@ class Cursor {
   void skip(size_t bytes) { need(bytes); pos_ += bytes; }
   bool eof() const { return pos_ >= size_; }
   size_t remaining() const { return size_ - pos_; }
+  size_t pos() const { return pos_; }
+  size_t size() const { return size_; }
+  const uint8_t *base() const { return base_; }
+  const std::string &path() const { return path_; }
+  int fd() const { return fd_; }
 
  private:
   void need(size_t bytes) const {
@@ -101,6 +106,7 @@ void parse_bitvector(Cursor &c, RawBitvector &bv) {
   if (bv.n == 0) return;
   uint64_t words = ceil_div(bv.n, 64);
   bv.bits.resize(words);
+  bv.file_off = c.pos();
   c.copy(bv.bits.data(), words * 8);
   c.get<uint64_t>();                        // rank9 _space
   uint64_t word_cnt = c.get<uint64_t>();
@@ -329,46 +335,83 @@ void parse_fm_protein(const std::string &path, HostIndex &h) {
     c.copy(P.end_marker_words.data(), ew * 8);
   }
   // ---- decode the BWT (Sequence_RunBlockOneTree::Access for i = 0, 1, ...: the compressed sequence is visited in order, so
-  // every wavelet node is read front to back and no rank is needed)
-  std::vector<uint64_t> cur(comp.node.size(), 0);
-  uint64_t produced = 0;
-  auto next_symbol = [&]() -> uint8_t {
-    if (comp.node.empty()) throw FormatError{"protein index without a compressed sequence"};
-    int ti = 0;
-    uint64_t code = 0;
-    int depth = 0;
-    while (ti != -1) {
-      if (ti < 0 || (size_t)ti >= comp.node.size() || cur[(size_t)ti] >= comp.node[(size_t)ti].n || ++depth > 16)
-        throw FormatError{"wavelet tree walk left the tree (node " + std::to_string(ti) + " of " + std::to_string(comp.node.size()) + ", bit " +
-                          std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? cur[(size_t)ti] : 0) + " of " +
-                          std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? comp.node[(size_t)ti].n : 0) + ", depth " + std::to_string(depth) +
-                          ", symbol " + std::to_string(produced) + " of " + std::to_string(comp.n) + ", n " + std::to_string(h.n) + ")"};
-      const unsigned bit = bit_at(comp.node[(size_t)ti], cur[(size_t)ti]++);
-      code = (code << 1) | bit;
-      ti = bit ? comp.child1[(size_t)ti] : comp.child0[(size_t)ti];
+  // every wavelet node is read front to back and no rank is needed).  Returns "" or what went wrong.
+  auto decode = [&](std::vector<uint8_t> &bwt) -> std::string {
+    std::vector<uint64_t> cur(comp.node.size(), 0);
+    uint64_t produced = 0;
+    std::string err;
+    auto next_symbol = [&]() -> int {
+      if (comp.node.empty()) { err = "protein index without a compressed sequence"; return -1; }
+      int ti = 0;
+      uint64_t code = 0;
+      int depth = 0;
+      while (ti != -1) {
+        if (ti < 0 || (size_t)ti >= comp.node.size() || cur[(size_t)ti] >= comp.node[(size_t)ti].n || ++depth > 16) {
+          err = "wavelet tree walk left the tree (node " + std::to_string(ti) + " of " + std::to_string(comp.node.size()) + ", bit " +
+                std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? cur[(size_t)ti] : 0) + " of " +
+                std::to_string(ti >= 0 && (size_t)ti < comp.node.size() ? comp.node[(size_t)ti].n : 0) + ", depth " + std::to_string(depth) +
+                ", symbol " + std::to_string(produced) + " of " + std::to_string(comp.n) + ", n " + std::to_string(h.n) + ")";
+          return -1;
+        }
+        const unsigned bit = bit_at(comp.node[(size_t)ti], cur[(size_t)ti]++);
+        code = (code << 1) | bit;
+        ti = bit ? comp.child1[(size_t)ti] : comp.child0[(size_t)ti];
+      }
+      ++produced;
+      if (code >= comp.alphabet.n) { err = "wavelet code outside the alphabet"; return -1; }
+      const uint8_t k = P.code_of[(unsigned char)comp.alphabet.list[code]];
+      if (k == 255) { err = "wavelet symbol outside the plain alphabet"; return -1; }
+      return k;
+    };
+    bwt.resize(h.n);
+    for (uint64_t bi = 0; bi < h.block_cnt; ++bi) {
+      const uint64_t lo = bi * h.b, hi = std::min(h.n, lo + h.b);
+      if (bit_at(h.use_run_block, bi)) {
+        const int k = next_symbol();
+        if (k < 0) return err;
+        for (uint64_t i = lo; i < hi; ++i) bwt[i] = (uint8_t)k;
+      } else {
+        for (uint64_t i = lo; i < hi; ++i) { const int k = next_symbol(); if (k < 0) return err; bwt[i] = (uint8_t)k; }
+      }
     }
-    ++produced;
-    if (code >= comp.alphabet.n) throw FormatError{"wavelet code outside the alphabet"};
-    const uint8_t k = P.code_of[(unsigned char)comp.alphabet.list[code]];
-    if (k == 255) throw FormatError{"wavelet symbol outside the plain alphabet"};
-    return k;
+    if (produced != comp.n) return "run-block component lengths do not add up";
+    // the partial sums must be those of the decoded string (FMIndex::Init, FMIndex.hpp:335-344)
+    std::vector<uint64_t> cnt(P.sigma + 1, 0);
+    for (uint64_t i = 0; i < h.n; ++i) ++cnt[bwt[i] + 1];
+    for (uint32_t k = 1; k <= P.sigma; ++k) cnt[k] += cnt[k - 1];
+    if (cnt != P.C) return "alphabet partial sums do not match the decoded BWT";
+    return "";
   };
-  P.bwt.resize(h.n);
-  for (uint64_t bi = 0; bi < h.block_cnt; ++bi) {
-    const uint64_t lo = bi * h.b, hi = std::min(h.n, lo + h.b);
-    if (bit_at(h.use_run_block, bi)) {
-      const uint8_t k = next_symbol();
-      for (uint64_t i = lo; i < hi; ++i) P.bwt[i] = k;
-    } else {
-      for (uint64_t i = lo; i < hi; ++i) P.bwt[i] = next_symbol();
+  const std::string derr = decode(P.bwt);
+  if (!derr.empty()) {
+    // A decode of a file that parsed field by field up to here should not fail; when it does, say what the failure was made of
+    // (round 3 saw this check fail twice in ~110 GPU-side test runs on files that parsed before and after): does this process's
+    // copy of the bit strings still equal the mapping, does the mapping equal what read() returns, does a second decode pass?
+    std::string note = "; forensics:";
+    size_t bad_copies = 0, first_bad = ~(size_t)0;
+    auto check_copy = [&](const RawBitvector &bv, size_t which) {
+      if (bv.n && memcmp(bv.bits.data(), c.base() + bv.file_off, ceil_div(bv.n, 64) * 8) != 0) { ++bad_copies; if (first_bad == ~(size_t)0) first_bad = which; }
+    };
+    check_copy(h.use_run_block, 0);
+    for (size_t k = 0; k < comp.node.size(); ++k) check_copy(comp.node[k], k + 1);
+    note += bad_copies ? " " + std::to_string(bad_copies) + " of " + std::to_string(comp.node.size() + 1) + " bit strings in memory differ from the file mapping (first: #" + std::to_string(first_bad) + ")"
+                       : " in-memory bit strings equal the file mapping";
+    {
+      std::vector<uint8_t> buf(c.size());
+      size_t got = 0;
+      while (got < buf.size()) { const ssize_t r = pread(c.fd(), buf.data() + got, buf.size() - got, (off_t)got); if (r <= 0) break; got += (size_t)r; }
+      if (got != buf.size()) note += ", pread() of the file came up short";
+      else {
+        size_t d = 0;
+        while (d < buf.size() && buf[d] == c.base()[d]) ++d;
+        note += d == buf.size() ? ", mapping equals pread()" : ", mapping differs from pread() at byte " + std::to_string(d);
+      }
     }
+    std::vector<uint8_t> again;
+    const std::string e2 = decode(again);
+    note += e2.empty() ? ", a second decode of the same memory PASSES" : ", a second decode fails too (" + e2 + ")";
+    throw FormatError{derr + note};
   }
-  if (produced != comp.n) throw FormatError{"run-block component lengths do not add up"};
-  // the partial sums must be those of the decoded string (FMIndex::Init, FMIndex.hpp:335-344)
-  std::vector<uint64_t> cnt(P.sigma + 1, 0);
-  for (uint64_t i = 0; i < h.n; ++i) ++cnt[P.bwt[i] + 1];
-  for (uint32_t k = 1; k <= P.sigma; ++k) cnt[k] += cnt[k - 1];
-  if (cnt != P.C) throw FormatError{"alphabet partial sums do not match the decoded BWT"};
 }
 
 std::string get_string(Cursor &c) {
@@ -437,6 +480,47 @@ bool is_protein(const std::string &prefix) {   // Classifier::IsProteinDatabase 
 }
 
 }  // namespace
+
+uint64_t index_digest(const HostIndex &h) {
+  uint64_t x = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t bytes) {
+    const uint8_t *b = (const uint8_t *)p;
+    // 8 bytes at a time (the bit strings of a large index are GBs): FNV-1a over words, then over the tail bytes
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); x = (x ^ w) * 1099511628211ull; }
+    for (; i < bytes; ++i) x = (x ^ b[i]) * 1099511628211ull;
+  };
+  auto num = [&](uint64_t v) { mix(&v, 8); };
+  auto bitvec = [&](const RawBitvector &bv) { num(bv.n); if (bv.n) mix(bv.bits.data(), ceil_div(bv.n, 64) * 8); };
+  auto wavelet = [&](const RawWavelet &w) { num(w.n); num((uint64_t)w.node_cnt); for (int k = 0; k < w.node_cnt; ++k) { num((uint64_t)w.children[k][0]); num((uint64_t)w.children[k][1]); bitvec(w.node[k]); } };
+  num(h.n); num(h.alphabet_bits); num(h.first_isa); num((uint64_t)(unsigned char)h.last_chr); num(h.last_code);
+  mix(h.C, sizeof(h.C));
+  num(h.b); num(h.block_cnt);
+  bitvec(h.use_run_block);
+  if (!h.prot.enabled) { wavelet(h.wavelet_seq); wavelet(h.run_block_seq); }
+  num((uint64_t)h.sample_rate); num(h.sample_size); num(h.precompute_width); num(h.precompute_size); num(h.adjusted_sa0);
+  num((uint64_t)h.sampled_bits); num(h.sampled_n);
+  mix(h.sampled_words.data(), h.sampled_words.size() * 8);
+  mix(h.ftab.data(), h.ftab.size() * 8);
+  num((uint64_t)h.selected_filter_rate);
+  mix(h.selected_rows.data(), h.selected_rows.size() * 8);
+  mix(h.selected_vals.data(), h.selected_vals.size() * 8);
+  num(h.has_end_marker);
+  if (h.prot.enabled) {
+    const ProteinPart &P = h.prot;
+    num(P.sigma); num(P.bits); mix(P.list, sizeof(P.list)); mix(P.code_of, sizeof(P.code_of));
+    mix(P.C.data(), P.C.size() * 8); mix(P.bwt.data(), P.bwt.size());
+    mix(P.end_marker_words.data(), P.end_marker_words.size() * 8); num((uint64_t)P.end_marker_bits); num(P.end_marker_n);
+  }
+  const Taxonomy &t = h.tax;
+  num(t.node_cnt); num(t.seq_cnt); num(t.extra_seq_cnt); num(t.root);
+  mix(t.parent.data(), t.parent.size() * 8); mix(t.rank.data(), t.rank.size()); mix(t.orig_taxid.data(), t.orig_taxid.size() * 8);
+  for (const auto &q : t.tax_name) { num(q.size()); mix(q.data(), q.size()); }
+  mix(t.seq_to_tax.data(), t.seq_to_tax.size() * 8);
+  for (const auto &q : t.seq_name) { num(q.size()); mix(q.data(), q.size()); }
+  num((uint64_t)h.params.min_hit_len); num((uint64_t)h.score_hit_len_adjust);
+  return x;
+}
 
 HostIndex *load_index(const std::string &prefix, const cfr_params *params) {
   const bool protein = is_protein(prefix);          // Classifier::IsProteinDatabase decides the sequence class (CentrifugerClass.cpp:1001-1004)

@@ -31,6 +31,7 @@ using RawWords = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
 struct RawBitvector {          // Bitvector_Plain as stored (its DS_Rank9 blocks are checked for size and skipped: the device image
   uint64_t n = 0;              // bits                             counts its own rank lines)
   RawWords bits;               // ceil(n/64)
+  uint64_t file_off = 0;       // where the words stand in the .1.cfr file (the decode's forensics compare the copy with the file again)
 };
 
 struct RawWavelet {            // Sequence_WaveletTree<Bitvector_Plain> for sigma=4: 3 nodes
@@ -98,6 +99,8 @@ struct FormatError { std::string msg; };
 struct IoError { std::string msg; };
 
 HostIndex *load_index(const std::string &prefix, const cfr_params *params);
+// FNV-1a over everything the parser produced (scalars, bit strings, tables, taxonomy): two opens of the same files must agree
+uint64_t index_digest(const HostIndex &h);
 
 
 }  // namespace cfr

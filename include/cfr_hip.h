@@ -116,6 +116,10 @@ const char *cfr_version(void);
 cfr_status cfr_index_open(const char *idx_prefix, const cfr_params *params, cfr_index **out);
 void cfr_index_destroy(cfr_index *idx);
 cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info);
+/* A 64-bit digest (FNV-1a) of everything cfr_index_open parsed - scalars, bit strings, tables, taxonomy, inferred parameters.
+ * Two opens of the same files with the same parameters give the same value (what the open/destroy stress test asserts); no
+ * reference counterpart. */
+cfr_status cfr_index_digest(const cfr_index *idx, uint64_t *digest);
 
 cfr_status cfr_device_count(int *count);
 cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out);

@@ -488,3 +488,13 @@ def test_host_dust_twins_equal_the_second_set_of_reference_dumps():
         s_ = bytes(b[int(o[i]):int(o[i + 1])])
         if len(s_) < 400:
             assert ora.dust_mask(s_) == want[rid], rid
+
+
+def test_digest_is_stable_and_tells_indexes_apart():
+    """cfr_index_digest: equal for every open of the same files, different between the golden index variants"""
+    prot = os.path.join(GOLDEN, "prot")
+    names = [os.path.join(GOLDEN, x) for x in ("f6", "f6_b1", "f6_b8", "f6_off3")] + [os.path.join(prot, x) for x in ("p2", "p2_b1_off2", "p3_b4")]
+    first = [capi.Index(p).digest() for p in names]
+    assert len(set(first)) == len(first)
+    for _ in range(20):
+        assert [capi.Index(p).digest() for p in names] == first
