@@ -51,7 +51,8 @@ def build_index(args, cache, device=None):
         g, cat = synth.make_genomes_fast(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step,
                                          threads=min(os.cpu_count() or 1, 64))
     else:
-        g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step)
+        g = synth.make_genomes(args.species, args.strains, args.genome_len, seed=args.seed, divergence_step=args.divergence_step,
+                               model=getattr(args, "divergence_model", "star"))
         cat = np.concatenate(g.seqs)
     np.save(os.path.join(cache, "genome_cat.npy"), cat)
     lens = np.array([len(s) for s in g.seqs], dtype=np.uint64)
@@ -255,7 +256,7 @@ def live_pmc(args, cache, gpu=0):
     import glob
     import shutil
     import tempfile
-    if args.mode != "se":
+    if args.mode not in ("se", "long"):
         return None
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
@@ -264,6 +265,7 @@ def live_pmc(args, cache, gpu=0):
     inner = [sys.executable, os.path.abspath(__file__), "--inner", "--reads", str(n_inner), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
              "--species", str(args.species), "--strains", str(args.strains), "--genome-len", str(args.genome_len), "--divergence-step", str(args.divergence_step),
              "--read-len", str(args.read_len), "--seed", str(args.seed), "--builder", args.builder, "--cache", args.cache] + (["--index-gbp", str(args.index_gbp)] if args.index_gbp else [])
+    inner += ["--divergence-model", getattr(args, "divergence_model", "star")] + (["--mode", "long"] if args.mode == "long" else [])
     env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n_inner), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")
     for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
         env.pop(k_, None)           # the child is a plain one-process run on this rank's GPU
@@ -272,10 +274,10 @@ def live_pmc(args, cache, gpu=0):
     vals, dur = {}, None
     work = tempfile.mkdtemp(prefix="cfr_pmc_", dir="/tmp")
     try:
-        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE"])):
+        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"])):
             d = os.path.join(work, f"pass{gi}")
             r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "k_search_chains_v2",
-                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
             if r.returncode != 0:
                 log("live PMC pass failed:", r.stderr.decode()[-400:])
                 return None
@@ -295,12 +297,97 @@ def live_pmc(args, cache, gpu=0):
         return {"source": f"live in this run: rocprofv3 --pmc (2 passes) around one {n_inner}-read launch of the same build, scaled per read",
                 "reads": n_inner, "rdreq": vals["TCC_EA0_RDREQ_sum"], "rdreq_32b": vals.get("TCC_EA0_RDREQ_32B_sum", 0.0),
                 "fetch_size_kib": vals.get("FETCH_SIZE", 0.0), "write_size_kib": vals["WRITE_SIZE"], "kernel_ms_profiled": dur, "prof": prof,
+                "l2_hit": (vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])) if vals.get("TCC_HIT_sum") is not None and (vals.get("TCC_HIT_sum", 0) + vals.get("TCC_MISS_sum", 0)) > 0 else None,
                 "kernel_source_sha": kernel_source_sha()}
     except Exception as e:
         log("live PMC unavailable:", repr(e))
         return None
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def live_pmc_dust(args, cache, gpu=0):
+    """Issue-side counters of the SDUST kernels (k_dust<true>: reads of A, C, G, T only - the kernel that carries the pre-step),
+    measured like live_pmc: this script re-executed (--inner --inner-dust: one 2 M-read step with cfr_device_index_set_dust(1))
+    under rocprofv3 --pmc, one pass per counter group.  Returns {counter: value, "ms": duration of that kernel} or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or args.mode != "se":
+        return None
+    n_inner = min(2_000_000, args.reads)
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--inner-dust", "--reads", str(n_inner), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--species", str(args.species), "--strains", str(args.strains), "--genome-len", str(args.genome_len), "--divergence-step", str(args.divergence_step),
+             "--read-len", str(args.read_len), "--seed", str(args.seed), "--builder", args.builder, "--cache", args.cache]
+    env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n_inner), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k_, None)
+    if gpu:
+        env["HIP_VISIBLE_DEVICES"] = str(gpu)
+    groups = (["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "GRBM_GUI_ACTIVE"],
+              ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM"])
+    out = {}
+    work = tempfile.mkdtemp(prefix="cfr_pmc_dust_", dir="/tmp")
+    try:
+        for gi, group in enumerate(groups):
+            d = os.path.join(work, f"pass{gi}")
+            r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "k_dust",
+                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            if r.returncode != 0:
+                log("live PMC pass (dust) failed:", r.stderr.decode()[-300:])
+                continue
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_dust<true>" in row["Kernel_Name"].replace(" ", ""):
+                        out[row["Counter_Name"]] = float(row["Counter_Value"])          # last dispatch = the timed step
+                        out["ms"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        return dict(out, reads=n_inner) if "SQ_INSTS_VALU" in out else None
+    except Exception as e:
+        log("live PMC (dust) unavailable:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def dust_roofline(pm, reads, dust_ms):
+    """The SDUST kernel is bound by its own instruction stream: its roofline is the VALU issue rate.  A wave64
+    VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md, wave scheduling), so peak = 1024 SIMDs x clock / 2
+    wave-instructions per second; clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time when that counter came back."""
+    if not pm:
+        return None
+    ms = pm["ms"]
+    clock = (pm["GRBM_GUI_ACTIVE"] / 8.0 / (ms / 1e3)) if pm.get("GRBM_GUI_ACTIVE") else 2.4e9
+    peak = 1024.0 * clock / 2.0
+    ach = pm["SQ_INSTS_VALU"] / (ms / 1e3)
+    r = {"bound": "valu", "kernel": "k_dust<true>", "unit": "G wave-instructions/s", "achieved": ach / 1e9, "peak": peak / 1e9, "frac": ach / peak,
+         "kernel_ms_profiled": ms, "reads_in_profiled_launch": pm["reads"], "kernel_ms_per_step_scaled": ms / pm["reads"] * reads,
+         "pre_step_ms_per_step_measured": dust_ms,
+         "clock_GHz": clock / 1e9, "valu_instructions_per_wave_and_base": pm["SQ_INSTS_VALU"] * 64.0 / (pm["reads"] * 150.0),
+         "waves_per_simd": (pm["SQ_WAVE_CYCLES"] * 4.0 / ((ms / 1e3) * clock * 1024.0)) if pm.get("SQ_WAVE_CYCLES") else None,
+         "wait_fraction_of_wave_cycles": (pm["SQ_WAIT_ANY"] / pm["SQ_WAVE_CYCLES"]) if pm.get("SQ_WAVE_CYCLES") and pm.get("SQ_WAIT_ANY") is not None else None,
+         "lds_instructions_per_valu": (pm["SQ_INSTS_LDS"] / pm["SQ_INSTS_VALU"]) if pm.get("SQ_INSTS_LDS") is not None else None,
+         "lds_bank_conflict_over_lds_active": (pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_ACTIVE_INST_LDS"]) if pm.get("SQ_ACTIVE_INST_LDS") else None,
+         "counters": {k_: v for k_, v in pm.items() if k_ not in ("ms", "reads")},
+         "note": "k_dust<true> under rocprofv3 --pmc (2 passes, one 2 M-read launch): VALU wave-instructions issued per second over what 1024 SIMD-32 units "
+                 "can issue (one wave64 VALU instruction per 2 cycles); SQ_* cycle counters are quad-cycles (x 4)"}
+    return r
+
+
+def mini_roofline(pmc, reads, search_ms):
+    """roofline object of a sub-result (same counter arithmetic as the main line's: 128-byte requests, WRITE_SIZE, 8 TB/s)"""
+    if not pmc:
+        return {"bound": "hbm", "kernel": "k_search_chains_v2", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": None, "frac": None, "traffic": None,
+                "note": "live PMC passes unavailable"}
+    per_read_rd = pmc["rdreq"] * BYTES_PER_RANDOM_REQUEST / pmc["reads"]
+    per_read_wr = pmc["write_size_kib"] * 1024 / pmc["reads"]
+    traffic = (per_read_rd + per_read_wr) * reads
+    ach = traffic / (search_ms / 1e3) / 1e9
+    req_s = pmc["rdreq"] / pmc["reads"] * reads / (search_ms / 1e3)
+    return {"bound": "hbm", "kernel": "k_search_chains_v2", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": search_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+            "traffic": traffic, "fabric_read_requests_per_read": pmc["rdreq"] / pmc["reads"], "l2_hit": pmc.get("l2_hit"),
+            "gather_frac_of_48G_requests_per_s": req_s / 48e9, "iteration_mix_per_read": pmc.get("prof"), "traffic_source": pmc["source"]}
 
 
 def live_pmc_protein(args, n):
@@ -345,14 +432,24 @@ def live_pmc_protein(args, n):
 
 def cache_key(args):
     return hashlib.md5((f"{args.species}-{args.strains}-{args.genome_len}-{args.seed}-{args.builder}" + (f"-{args.divergence_step}" if args.divergence_step != 0.01 else "")
-                        + ("-fastgen" if args.index_gbp else "")).encode()).hexdigest()[:10]
+                        + ("-fastgen" if args.index_gbp else "") + ("-" + args.divergence_model if getattr(args, "divergence_model", "star") != "star" else "")).encode()).hexdigest()[:10]
 
 
-def strains_config(torch, capi, ora, args, device):
-    """The data-sensitivity case as a sub-result: 25 species x 20 strains 0.1 % apart x 2 Mbp (1 Gbp), the metric's reads
-    (10 M x 150 bp SE, -k 1): ranges of ~20 rows per hit (wide text mode in the search, k_tail_heavy in the tail)."""
+STRAIN_WORKLOADS = {
+    # name: (species, strains per species, genome length, divergence step, genome model, description)
+    "strains20": (25, 20, 2_000_000, 0.001, "star", "25 species x 20 strains 0.1 % apart"),
+    "strains200": (10, 200, 500_000, 0.0005, "tree", "10 species x 200 strains, a binary phylogeny with 0.05 % new substitutions per edge (neighbours 0.05-0.1 % apart)"),
+}
+
+
+def strains_config(torch, capi, ora, args, device, name="strains20"):
+    """The data-sensitivity cases as sub-results: many near-identical strains per species (1 Gbp), the metric's reads (10 M x 150 bp SE,
+    -k 1).  strains20: ranges of ~20 rows per hit (wide text mode in the search, k_tail_heavy in the tail).  strains200: what a
+    redundant database (RefSeq / GTDB species with hundreds of genomes, /root/reference/README.md:13) looks like - ranges of ~200 rows,
+    strided locate (Classifier.hpp:640-666).  Checked against the C oracle's TSV lines; roofline + iteration mix from live PMC passes."""
     a2 = argparse.Namespace(**vars(args))
-    a2.species, a2.strains, a2.genome_len, a2.divergence_step, a2.index_gbp = 25, 20, 2_000_000, 0.001, 0.0
+    a2.species, a2.strains, a2.genome_len, a2.divergence_step, a2.divergence_model, desc = STRAIN_WORKLOADS[name]
+    a2.index_gbp = 0.0
     cache = os.path.join(args.cache, cache_key(a2))
     prefix = build_index(a2, cache, device)
     torch.cuda.empty_cache()
@@ -392,13 +489,18 @@ def strains_config(torch, capi, ora, args, device):
     res, mat = capi.expand_compact(res_pin.array[:nchk], mat_pin.array[:nchk], 1) if compact else (res_pin.array, mat_pin.array)
     same = all(idx.format_tsv("r", res[i], mat) == oo.format("r", ores[i]) for i in range(nchk))
     out = {"value": n * steps / el, "unit": "reads/s", "ms_per_step": 1000 * el / steps, "steps": steps,
-           "workload": f"{idx.info().n/1e9:.2f} Gbp index of 25 species x 20 strains 0.1 % apart, {n} x {args.read_len} bp SE reads, -k 1, inputs resident in HBM",
+           "workload": f"{idx.info().n/1e9:.2f} Gbp index of {desc}, {n} x {args.read_len} bp SE reads, -k 1, inputs resident in HBM",
            "search_ms": st.search_ms, "tail_ms": st.tail_ms, "classified_fraction": float((res_pin.array["n_match"] > 0).mean()),
            "tsv_lines_equal_oracle_on_first": nchk, "equals_oracle": bool(same)}
     oo.close()
     res_pin.free()
     mat_pin.free()
     dev.close()
+    del reads_d, offs_d
+    torch.cuda.empty_cache()
+    if not args.no_pmc:
+        a2.mode, a2.reads = "se", n
+        out["roofline"] = mini_roofline(live_pmc(a2, cache, device.index or 0), n, st.search_ms)
     return out
 
 
@@ -620,6 +722,79 @@ def protein_mode(torch, capi, args, device):
     dev.close()
 
 
+def sub_config_40gbp(args, cfg):
+    """BASELINE configs[3] (cfg4) / configs[4] (cfg5) on this one GPU, as a sub-result of the default line: `bench.py --config cfg4|cfg5
+    --sub-result` in a process of its own (the 249 GB image needs the GPU to itself; the index - 40 Gbp, written once by the native
+    writer in ~4 min - is shared through the cache).  What comes back is that run's own JSON line, cut down to the fields that matter
+    here.  Skipped, with the reason, on a box that cannot hold it."""
+    import shutil
+    try:
+        import torch
+        need = []
+        free_b, total_b = torch.cuda.mem_get_info()
+        if total_b < 270e9:
+            need.append(f"HBM {total_b/1e9:.0f} GB < 270 GB (the 40 Gbp image takes 249 GB)")
+        avail = None
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+        lim = None
+        for f in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+            try:
+                v = open(f).read().strip()
+                if v.isdigit():
+                    lim = int(v)
+                    break
+            except OSError:
+                pass
+        a2 = argparse.Namespace(**vars(args))
+        a2.index_gbp, a2.divergence_model = 40.0, "star"
+        a2.species = max(1, int(round(a2.index_gbp * 1e9 / (a2.strains * a2.genome_len))))
+        have_index = os.path.exists(os.path.join(args.cache, cache_key(a2), "idx.done"))
+        host_need = 60e9 if have_index else 250e9      # building keeps the suffix array in host memory (186 GiB) beside the text's file mapping
+        host_have = min(x for x in (avail, lim) if x is not None) if (avail is not None or lim is not None) else None
+        if host_have is not None and host_have < host_need:
+            need.append(f"host memory {host_have/1e9:.0f} GB < {host_need/1e9:.0f} GB")
+        os.makedirs(args.cache, exist_ok=True)
+        disk = shutil.disk_usage(args.cache).free
+        if disk < (30e9 if have_index else 110e9):
+            need.append(f"{args.cache}: {disk/1e9:.0f} GB free (text 40 GB + index files 17 GB + samples)")
+        if need:
+            return {"skipped": "; ".join(need)}
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--sub-result", "--cache", args.cache, "--seed", str(args.seed)] + (["--no-pmc"] if args.no_pmc else [])
+        if cfg == "cfg5":
+            cmd.append("--no-cpu-baseline")      # (20 000 long reads through the reference binary at 40 Gbp take minutes; parity of this leg = the C oracle on 4000 reads)
+        env = dict(os.environ)
+        for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+            env.pop(k_, None)
+        t0 = time.time()
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=2400 if not have_index else 1500)
+        wall = time.time() - t0
+        line = None
+        for ln in r.stdout.decode().splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+        if r.returncode != 0 or line is None:
+            return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr.decode()[-600:], "seconds": wall}
+        d = json.loads(line)
+        roof = d.get("roofline") or {}
+        keep = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "workload": d["config"]["workload"],
+                "index_bp": d["config"].get("index_bp"), "timed_entry": d["config"].get("timed_entry"), "stage_ms": d.get("stage_ms"),
+                "classified_fraction": d.get("classified_fraction"), "bases_per_s": d.get("bases_per_s"),
+                "equals_oracle": (d.get("parity_oracle") or {}).get("equals_oracle"), "equals_oracle_on_first": (d.get("parity_oracle") or {}).get("reads"),
+                "parity_vs_reference_binary": {k_: (d.get("parity") or {}).get(k_) for k_ in ("reads", "timed_entry_tsv_identical_to_reference_no_dust", "tsv_identical_to_reference")} if d.get("parity") else None,
+                "cpu_baseline": {k_: (d.get("cpu_baseline") or {}).get(k_) for k_ in ("value", "unit", "cores", "kind", "sample")} if d.get("cpu_baseline") else None,
+                "roofline": {k_: roof.get(k_) for k_ in ("bound", "kernel", "peak", "unit", "achieved", "frac", "traffic", "kernel_ms", "fabric_read_requests_per_read", "l2_hit",
+                                                        "frac_useful_bytes", "x_reference_algorithm", "gather", "iteration_mix_per_read", "traffic_source")},
+                "index": d.get("index"), "multi_rank_load": d.get("multi_rank_load"), "seconds": wall,
+                "note": f"`bench.py --config {cfg}` in its own process on this GPU: BASELINE {'configs[3]' if cfg == 'cfg4' else 'configs[4]'} per rank (the 8-GPU job is 8 such ranks, index replicated)"}
+        return keep
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -651,7 +826,7 @@ def main():
     ap.add_argument("--results", choices=["compact", "wide"], default="compact",
                     help="result layout of the timed entry: compact = cfr_classify_batch_resident_compact (20 + 12 bytes per read / match slot "
                          "cross PCIe), wide = cfr_classify_batch_resident (40 + 24); the other one is reported under other_result_layout")
-    ap.add_argument("--workload", choices=["cfg2", "strains20"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "strains20", "strains200"], default="cfg2",
                     help="cfg2 = the metric's index (50 species x 5 strains 1 %% apart); strains20 = the data-sensitivity case: "
                          "25 species x 20 strains 0.1 %% apart x 2 Mbp (ranges of ~20 rows per hit: wide text mode, team fold)")
     ap.add_argument("--config", choices=["cfg2", "cfg3", "cfg4", "cfg5"], default=None,
@@ -660,21 +835,29 @@ def main():
                          "cfg5 = configs[4]: 40 Gbp index, long reads 5-20 kbp, 2.5 M per rank over the timed steps (312 500 per step: the bases of one "
                          "step are 3.9 GB beside a 245 GB image)")
     ap.add_argument("--sdust-steps", type=int, default=5, help="timed steps of the legs with the SDUST pre-step on the device")
+    ap.add_argument("--divergence-model", choices=["star", "tree"], default="star", help="synth.make_genomes model (tree: strain k descends from strain (k-1)//2)")
+    ap.add_argument("--inner-dust", action="store_true", help=argparse.SUPPRESS)   # child of the SDUST PMC passes: the inner step with the pre-step on
+    ap.add_argument("--sub-result", action="store_true", help=argparse.SUPPRESS)   # child of the default run: one BASELINE config as a compact sub-result
+    ap.add_argument("--no-40gbp", action="store_true", help="skip the cfg4 / cfg5 legs (40 Gbp index on this GPU) of the default run")
     args = ap.parse_args()
     if args.config == "cfg3":
         args.mode = "pe"
-    elif args.config == "cfg4":
-        args.index_gbp, args.reads = 40.0, 12_500_000
+    elif args.config == "cfg4":        # (an explicit --index-gbp / --reads wins: the multi-rank test runs this preset on a 1 Gbp index)
+        args.index_gbp = args.index_gbp or 40.0
+        if args.reads == 10_000_000:
+            args.reads = 12_500_000
     elif args.config == "cfg5":
-        args.index_gbp, args.mode, args.reads = 40.0, "long", 312_500
+        args.index_gbp, args.mode = args.index_gbp or 40.0, "long"
+        if args.reads == 10_000_000:
+            args.reads = 312_500
         if args.steps == 3:
             args.steps = 8          # 8 x 312 500 = cfg5's 2.5 M long reads per rank
     if args.index_gbp >= 4 and args.cpu_sample == 2_000_000:
         args.cpu_sample = 400_000       # the reference loads a 40 Gbp index for minutes per run: a smaller sample, no thread sweep
     if args.config in ("cfg4", "cfg5"):
         args.no_extra_configs = True
-    if args.workload == "strains20":
-        args.species, args.strains, args.genome_len, args.divergence_step = 25, 20, 2_000_000, 0.001
+    if args.workload in STRAIN_WORKLOADS:
+        args.species, args.strains, args.genome_len, args.divergence_step, args.divergence_model = STRAIN_WORKLOADS[args.workload][:5]
     if args.index_gbp:
         args.species = max(1, int(round(args.index_gbp * 1e9 / (args.strains * args.genome_len))))
 
@@ -759,7 +942,17 @@ def main():
     total_bases = int(offs_h[-1])
     t0 = time.time()
     idx = capi.Index(prefix, capi.default_params(max_result=k))
-    dev = capi.DeviceIndex(idx, local_rank)
+    if share_gpu and world > 1:
+        # every rank on ONE device (a test of the multi-rank code path, not a configuration): the images are built one rank after the
+        # other and without the tables that are sized from the free HBM (each rank would otherwise see the memory the others are about to take)
+        opts = capi.default_device_options(ftabx_width=13, loc_memo_gb=0.0)
+        dev = None
+        for r_ in range(world):
+            if r_ == rank:
+                dev = capi.DeviceIndex(idx, local_rank, opts)
+            dist.barrier()
+    else:
+        dev = capi.DeviceIndex(idx, local_rank)
     info = dev.info()
     log(f"rank {rank}: index n={info.n} b={info.block_size} loaded; device image {info.device_bytes/1e6:.0f} MB in {time.time()-t0:.1f}s")
 
@@ -790,6 +983,8 @@ def main():
             results[:] = r
             matches[:len(m)] = m
 
+    if args.inner and args.inner_dust:
+        dev.set_dust(True)                               # (child of the SDUST counter passes: the step with the pre-step on the device)
     for _ in range(args.warmup):
         step()
     if dist is not None:
@@ -882,6 +1077,16 @@ def main():
     threads = min(os.cpu_count() or 1, 64)
     ores, cnt = o.classify(sample, soffs, sample2, soffs if paired else None, threads=threads, counters=True)
     c = cnt.as_dict()
+    # the timed entry's results against the C oracle on that sample (every field of every read; the first 5000 also as TSV lines)
+    same_fields = all((int(results[i]["score"]), int(results[i]["secondary_score"]), int(results[i]["hit_length"]), int(results[i]["query_length"]), int(results[i]["n_match"])) ==
+                      (ores[i].score, ores[i].secondaryScore, ores[i].hitLength, ores[i].queryLength, ores[i].nmatch) for i in range(ns))
+    same_tsv = all(idx.format_tsv("r", results[i], matches) == o.format("r", ores[i]) for i in range(min(ns, 5000)))
+    out["parity_oracle"] = {"reads": ns, "tsv_lines": min(ns, 5000), "equals_oracle": bool(same_fields and same_tsv),
+                            "note": "timed entry (no pre-step) vs oracle/liboracle.so Query on the first reads of the step batch: score, second score, hit length, query length, match count of every read; TSV lines of the first 5000"}
+    try:
+        out["index"] = json.load(open(prefix + ".build.json"))
+    except Exception:
+        pass
     # reference-algorithm bytes of the search part = everything except the locate part
     bytes_search = cnt.search_bytes() / ns
     bytes_locate = cnt.locate_bytes() / ns
@@ -940,6 +1145,8 @@ def main():
                          "note": "fabric read requests per second over tools/gather_bench's ceiling for dependent random gathers at this footprint"},
               "note": "achieved = bytes the kernel moves over the fabric (PMC TCC_EA0_RDREQ x 128 B calibrated + WRITE_SIZE, one 2 M-read launch "
                       "under rocprofv3 --pmc, scaled per read) / kernel time of the timed steps (HIP events on the library stream)"})
+          roof["l2_hit"] = pmc.get("l2_hit")
+          roof["frac_counter_traffic"] = roof["frac"]
           if pmc.get("prof"):
               pr = pmc["prof"]
               useful = (16 * (pr.get("table", 0) + pr.get("table10", 0)) + 48 * pr.get("ext_two_records", 0) + 24 * (pr.get("ext", 0) - pr.get("ext_two_records", 0))
@@ -947,8 +1154,16 @@ def main():
               roof["useful_bytes_per_read"] = useful
               roof["iteration_mix_per_read"] = pr
               roof["fetched_over_useful"] = (per_read_rd + per_read_wr) / useful if useful else None
+              roof["frac_useful_bytes"] = (useful * args.reads / (search_ms / 1e3) / 1e9) / HBM_PEAK_GBS
       else:
           roof.update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC source available (rocprofv3 failed and no committed profile for this workload)"})
+      # ONE place for the three yardsticks: `frac` / frac_counter_traffic = bytes the counters saw cross the fabric
+      # (128-byte lines) over the HBM peak; frac_useful_bytes = the bytes of those lines the kernel consumes; x_reference_algorithm =
+      # SURVEY.md section 8(d)'s algorithmic bytes of the REFERENCE's data structures over this kernel's time, as a multiple of the
+      # peak (> 1: the kernel does not perform that memory work - K-mer table, text mode, step function replace it; results identical)
+      roof["x_reference_algorithm"] = ref_alg_gbs / HBM_PEAK_GBS
+      roof["yardsticks"] = ("frac = frac_counter_traffic: fabric bytes by PMC / 8 TB/s; frac_useful_bytes: bytes consumed / 8 TB/s; x_reference_algorithm: "
+                            "SURVEY 8(d) bytes of the reference algorithm / kernel time / 8 TB/s (an algorithmic speed-up, not a bandwidth)")
       roof["reference_algorithm"] = {
           "bytes_per_read": bytes_search, "GBs_if_the_reference_traffic_were_moved": ref_alg_gbs, "x_of_hbm_peak": ref_alg_gbs / HBM_PEAK_GBS,
           "note": "SURVEY.md section 8(d) figure: bytes the REFERENCE algorithm reads for the same searches (24 B/bit-rank, 8 B/bit-access, 16 B/ftab, "
@@ -1047,6 +1262,23 @@ def main():
             out["pcie_inclusive"]["pinned_value"] = args.reads / (time.perf_counter() - t0)
             out["pcie_inclusive"]["pinned_note"] = f"{args.reads} reads, bases / offsets / results / matches all in cfr_host_alloc memory"
             out["pcie_inclusive"]["host_entry_equals_resident_entry"] = bool(res_keep.tobytes() == results[:nb].tobytes()) and pageable_equal
+            # the same batch handed over PACKED (cfr_classify_batch_packed: 0.5 byte per base instead of 1 over the link); packing on host threads timed apart
+            pk = capi.PinnedArray((total_bases + 15) // 16, np.uint64)
+            capi.pack_reads(pb.array, threads=min(ncpu, 64), out=pk.array)
+            t0 = time.perf_counter()
+            capi.pack_reads(pb.array, threads=min(ncpu, 64), out=pk.array)
+            t_pack = time.perf_counter() - t0
+            dev.classify_packed(pk.array, po.array, results=results, matches=matches)
+            bestp = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                dev.classify_packed(pk.array, po.array, results=results, matches=matches)
+                bestp = min(bestp, time.perf_counter() - t0)
+            out["pcie_inclusive"]["packed_pinned_value"] = args.reads / bestp
+            out["pcie_inclusive"]["packed_pinned_note"] = (f"cfr_classify_batch_packed: {args.reads} reads as 2-bit blocks + validity bits (75 B/read + 8 B offset up, 64 B/read down), "
+                                                           f"every buffer in cfr_host_alloc memory, best of 3; cfr_pack_reads of the batch on {min(ncpu, 64)} host threads: {t_pack*1e3:.1f} ms = {args.reads/t_pack:.3g} reads/s (not inside)")
+            out["pcie_inclusive"]["packed_entry_equals_resident_entry"] = bool(res_keep.tobytes() == results[:nb].tobytes())
+            out["pcie_inclusive"]["host_pack_reads_per_s"] = args.reads / t_pack
             # what a host caller with the reference's default options gets: unmasked reads in pinned host memory, SDUST on the device
             dev.set_dust(True)
             dev.classify(pb.array, po.array, results=results, matches=matches)
@@ -1056,7 +1288,13 @@ def main():
             out["pcie_inclusive"]["pinned_with_sdust_value"] = args.reads * args.sdust_steps / (time.perf_counter() - t0)
             out["pcie_inclusive"]["pinned_with_sdust_note"] = (f"cfr_classify_batch with cfr_device_index_set_dust(1): {args.reads} unmasked reads from cfr_host_alloc memory, "
                                                                f"results to cfr_host_alloc memory, {args.sdust_steps} steps")
+            dev.classify_packed(pk.array, po.array, results=results, matches=matches)
+            t0 = time.perf_counter()
+            for _ in range(args.sdust_steps):
+                dev.classify_packed(pk.array, po.array, results=results, matches=matches)
+            out["pcie_inclusive"]["packed_pinned_with_sdust_value"] = args.reads * args.sdust_steps / (time.perf_counter() - t0)
             dev.set_dust(False)
+            pk.free()
             pb.free()
             po.free()
         gpu_tsv = capi.tsv_header() + b"".join(idx.format_tsv(f"r{i}", r2[i], m2) for i in range(nb))
@@ -1085,12 +1323,32 @@ def main():
                                  "the second check hands unmasked reads to cfr_classify_batch with SDUST on the device vs the reference's default run"}
         out["kernel_vs_e2e_cpu"] = value / world / cpu_rate      # resident-input device step over the END-TO-END reference: not like for like (see e2e_cli.speedup)
         cli_job = (files, ref_tsv, t_full, nb, ncpu)
+    if args.sub_result and args.config == "cfg4":
+        # what 8 ranks of one node do to each other at load time on the HOST side: 8 processes open this index at once (cfr_index_open:
+        # the 15 GB .1.cfr through the page cache into 8 private copies) against one process alone.  (The device half - 8 images
+        # derived side by side - needs 8 GPUs.)
+        try:
+            code = ("import sys,time; sys.path.insert(0, %r); from centrifuger_amd import capi; t0=time.time(); i=capi.Index(%r); d=i.digest(); print(time.time()-t0, d)" % (ROOT, prefix))
+            def opens(k_):
+                t0_ = time.time()
+                ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(k_)]
+                outs = [p_.communicate()[0].decode().split() for p_ in ps]
+                return time.time() - t0_, [float(o_[0]) for o_ in outs if len(o_) == 2], {o_[1] for o_ in outs if len(o_) == 2}
+            w1, t1, d1 = opens(1)
+            w8, t8, d8 = opens(8)
+            out["multi_rank_load"] = {"index_open_alone_s": t1[0] if t1 else None, "index_open_8_at_once_s_each": t8, "wall_8_at_once_s": w8,
+                                      "digests_equal": len(d1 | d8) == 1 and len(t8) == 8,
+                                      "note": "cfr_index_open of this index in 1 process and in 8 processes started together (process start and imports included in the wall figure, not in the per-open ones)"}
+        except Exception as e:
+            out["multi_rank_load"] = {"error": repr(e)}
     # ---- the live PMC passes need the GPU to themselves (the K-mer table is sized from the free HBM): this process lets go of
     # its image and reads first, so the child builds exactly the image that was timed
     dev.close()
     del reads_d, reads2_d
     torch.cuda.empty_cache()
     out["roofline"] = build_roofline(live_pmc(args, cache, local_rank) if not args.no_pmc else None)    # (rank 0's GPU; the other ranks have left)
+    if not args.no_pmc and args.mode == "se" and not args.sub_result:
+        out["with_device_sdust"]["roofline"] = dust_roofline(live_pmc_dust(args, cache, local_rank), args.reads, ms_with_dust - 1000.0 * elapsed / args.steps)
     if cli_job is not None:
         # ---- end-to-end wall clock of the drop-in command line on the same file (parse + dust + device + TSV, index load included);
         # runs with the GPU to itself, like a user's run
@@ -1117,10 +1375,16 @@ def main():
             except Exception as e:
                 out["other_configs"][m] = {"error": repr(e)}
         if args.workload == "cfg2" and not args.index_gbp:
-            try:
-                out["other_configs"]["strains20"] = strains_config(torch, capi, ora, args, device)
-            except Exception as e:
-                out["other_configs"]["strains20"] = {"error": repr(e)}
+            for wname in ("strains20", "strains200"):
+                try:
+                    out["other_configs"][wname] = strains_config(torch, capi, ora, args, device, wname)
+                except Exception as e:
+                    out["other_configs"][wname] = {"error": repr(e)}
+            if not args.no_40gbp:
+                # BASELINE configs[3] / configs[4] on ONE GPU: the 40 Gbp index (written once by the native writer, ~4 min) and this
+                # rank's share of the reads - 12.5 M x 150 bp per step, 312 500 long reads per step - each in a process of its own
+                for cfg in ("cfg4", "cfg5"):
+                    out["other_configs"][cfg + "_1gpu"] = sub_config_40gbp(args, cfg)
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -90,7 +90,7 @@ EXPORTS = [
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
-    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest",
+    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest", "cfr_pack_reads", "cfr_classify_batch_packed",
 ]
 
 _lib = None
@@ -383,6 +383,24 @@ class DeviceIndex:
             _check(st)
             return results, matches[:nm.value]
 
+    def classify_packed(self, packed1, offsets1, packed2=None, offsets2=None, results=None, matches=None):
+        """cfr_classify_batch_packed: the bases as packed blocks (pack_reads) instead of ASCII; same results as classify()"""
+        packed1, offsets1, packed2, offsets2 = _u64(packed1), _u64(offsets1), _u64(packed2), _u64(offsets2)
+        n = len(offsets1) - 1
+        if results is None:
+            results = np.zeros(n, dtype=RESULT_DTYPE)
+        if matches is None:
+            matches = np.zeros(max(16, max(1, self.index.params.max_result) * n), dtype=MATCH_DTYPE)
+        while True:
+            nm = C.c_size_t(0)
+            st = lib().cfr_classify_batch_packed(self._d, _p(packed1), _p(offsets1), _p(packed2), _p(offsets2), C.c_size_t(n),
+                                                 _p(results), _p(matches), C.c_size_t(len(matches)), C.byref(nm))
+            if st == CFR_ERR_CAPACITY:
+                matches = np.zeros(int(nm.value) + 16, dtype=MATCH_DTYPE)
+                continue
+            _check(st)
+            return results, matches[:nm.value]
+
     def compact_wide(self):
         """cfr_compact_wide_reads: (read_index, results, matches) of the reads the last compact call flagged CFR_COMPACT_WIDE"""
         n = C.c_size_t(0)
@@ -466,6 +484,16 @@ def dust_mask(bases, offsets, threads=1, literal=False):
     fn = lib().cfr_dust_mask_batch_literal if literal else lib().cfr_dust_mask_batch
     _check(fn(_p(bases), _p(offsets), C.c_size_t(len(offsets) - 1), C.c_int(threads)))
     return bases
+
+
+def pack_reads(bases, threads=1, out=None):
+    """cfr_pack_reads: uint64 blocks of 16 characters (2-bit codes + validity bits) of a flat ASCII read buffer"""
+    bases = _u8(bases)
+    nblk = (len(bases) + 15) // 16
+    if out is None:
+        out = np.empty(max(nblk, 1), dtype=np.uint64)
+    _check(lib().cfr_pack_reads(_p(bases), C.c_uint64(len(bases)), C.c_int(threads), _p(out)))
+    return out[:nblk]
 
 
 def tsv_header() -> bytes:

@@ -189,6 +189,8 @@ int main(int argc, char *argv[]) {
       }
       return path;
     };
+    uint64_t tree_root = 1;                  // Taxonomy::FindRoot (Taxonomy.hpp:426-433): the first node that is its own parent
+    for (const auto &kv : parent_of) if (kv.second == kv.first) { tree_root = kv.first; break; }
     std::map<std::string, size_t> first_at;
     for (const std::string &ln : lines) {   // (every tax id the table mentions keeps its lineage in the tree, Taxonomy.hpp:275-300)
       if (ln.empty() || ln[0] == '#') continue;
@@ -202,10 +204,16 @@ int main(int argc, char *argv[]) {
         seq_name.push_back(nm);
         seq_taxid.push_back(tid);
       } else {
-        const auto pa = lineage(seq_taxid[it->second]), pb = lineage(tid);
-        long i = (long)pa.size() - 1, j = (long)pb.size() - 1;
-        for (; i >= 0 && j >= 0; --i, --j) if (pa[(size_t)i] != pb[(size_t)j]) break;
-        seq_taxid[it->second] = (i == (long)pa.size() - 1) ? pa.back() : pa[(size_t)i + 1];
+        // (an id the tree does not hold has the root as its whole lineage there, Taxonomy.hpp:977-984, and two lineages that part
+        // at the very top meet in the root, :345-348)
+        const uint64_t a = seq_taxid[it->second];
+        if (!parent_of.count(a) || !parent_of.count(tid)) seq_taxid[it->second] = tree_root;
+        else {
+          const auto pa = lineage(a), pb = lineage(tid);
+          long i = (long)pa.size() - 1, j = (long)pb.size() - 1;
+          for (; i >= 0 && j >= 0; --i, --j) if (pa[(size_t)i] != pb[(size_t)j]) break;
+          seq_taxid[it->second] = (i == (long)pa.size() - 1) ? tree_root : pa[(size_t)i + 1];
+        }
       }
     }
   }

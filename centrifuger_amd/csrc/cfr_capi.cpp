@@ -9,6 +9,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "cfr_build.hpp"
 #include "cfr_device.hpp"
@@ -272,6 +273,56 @@ cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uin
   CFR_ENTER(d, "cfr_classify_batch");
   return guarded([&]() -> cfr_status {
     d->d->classify_host(bases1, offsets1, bases2, offsets2, n, results, matches, match_cap, n_matches);
+    return CFR_OK;
+  });
+}
+
+// cfr_pack_reads: the packed form of a read buffer (what k_pack_reads makes on the device), on host threads
+cfr_status cfr_pack_reads(const uint8_t *bases, uint64_t total, int threads, uint64_t *packed) {
+  if ((total && !bases) || !packed) return bad_arg("cfr_pack_reads: null argument");
+  const uint64_t nblk = (total + 15) / 16;
+  if (threads < 1) threads = 1;
+  auto conv4 = [](uint32_t x, uint32_t &code8, uint32_t &valid4) {        // 4 ASCII bytes -> 4 two-bit codes + 4 validity bits (the device's conv4)
+    uint32_t k = (x >> 1) & 0x03030303u;
+    k ^= (k >> 1) & 0x01010101u;
+    const uint32_t b0 = k & 0x01010101u, b1 = (k >> 1) & 0x01010101u;
+    const uint32_t expect = 0x41414141u + b0 * 2u + b1 * 6u + (b0 & b1) * 11u;
+    const uint32_t d = x ^ expect;
+    const uint32_t nz = (((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) & 0x80808080u;
+    const uint32_t ok = ~nz & 0x80808080u;
+    valid4 = ((ok >> 7) | (ok >> 14) | (ok >> 21) | (ok >> 28)) & 0xfu;
+    code8 = (k | (k >> 6) | (k >> 12) | (k >> 18)) & 0xffu;
+  };
+  auto work = [&](int tid) {
+    const uint64_t lo = nblk * (uint64_t)tid / (uint64_t)threads, hi = nblk * (uint64_t)(tid + 1) / (uint64_t)threads;
+    for (uint64_t b = lo; b < hi; ++b) {
+      uint32_t w[4] = {0, 0, 0, 0};
+      const uint64_t a = b << 4;
+      if (a + 16 <= total) memcpy(w, bases + a, 16);
+      else memcpy(w, bases + a, (size_t)(total - a));               // bytes past the end: zero = not a symbol
+      uint32_t c = 0, vv = 0;
+      for (int q = 0; q < 4; ++q) { uint32_t c8, v4; conv4(w[q], c8, v4); c |= c8 << (8 * q); vv |= v4 << (4 * q); }
+      packed[b] = (uint64_t)c | ((uint64_t)vv << 32);
+    }
+  };
+  if (threads == 1 || nblk < 4096) { threads = 1; work(0); }
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  return CFR_OK;
+}
+
+cfr_status cfr_classify_batch_packed(cfr_dev_index *d, const uint64_t *packed1, const uint64_t *offsets1, const uint64_t *packed2,
+                                     const uint64_t *offsets2, size_t n, cfr_result *results, cfr_match *matches, size_t match_cap,
+                                     size_t *n_matches) {
+  if (!d || (n && (!packed1 || !offsets1 || !results))) return bad_arg("cfr_classify_batch_packed: null argument");
+  if ((packed2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch_packed: packed2/offsets2 must both be given");
+  if (d->d->host().prot.enabled) return bad_arg("cfr_classify_batch_packed: a protein index needs the characters themselves (DnaToAa tells non-symbols apart): use cfr_classify_batch");
+  CFR_ENTER(d, "cfr_classify_batch_packed");
+  return guarded([&]() -> cfr_status {
+    d->d->classify_host_packed(packed1, offsets1, packed2, offsets2, n, results, matches, match_cap, n_matches);
     return CFR_OK;
   });
 }

@@ -37,7 +37,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
 };
 
 }  // namespace
@@ -527,6 +527,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       if (protein) {
         // every stop of the walk (k_collect_stops_prot), sorted by position on the device
         const uint64_t nsamp_p = (h.n + h.sample_rate - 1) / h.sample_rate, total = nsamp_p + h.prot.end_marker_n;
+        if (total >= (1ull << 31)) throw HipError{"protein index too large for the stop sort", -5};       // (hipCUB takes an int count)
         uint64_t *d_pos = (uint64_t *)talloc(total * 8), *d_val = (uint64_t *)talloc(total * 8);
         uint64_t *d_pos2 = (uint64_t *)talloc(total * 8), *d_val2 = (uint64_t *)talloc(total * 8);
         k_collect_stops_prot<<<(unsigned)std::min<uint64_t>((total + 255) / 256, 1u << 20), 256, 0, stream_>>>(view_, nsamp_p, d_pos, d_val);
@@ -539,7 +540,6 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
         HIP_CHECK(hipMemcpyAsync(hp.data(), d_pos2, total * 8, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipMemcpyAsync(hv.data(), d_val2, total * 8, hipMemcpyDeviceToHost, stream_));
         HIP_CHECK(hipStreamSynchronize(stream_));
-        if (total >= (1ull << 31)) throw HipError{"protein index too large for the stop sort", -5};
         if (hp.empty() || hp[0] != 0) bp.emplace_back(0, h.adjusted_sa0);       // (position 0 is the row firstISA: listed when that row is a sampled one)
         for (uint64_t k = 0; k < total && hp[k] != ~0ull; ++k) bp.emplace_back(hp[k], hv[k]);
       } else {
@@ -1249,18 +1249,27 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipMemsetAsync(cap_all + n, 0, 8, stream_));
     k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap_all);
     exclusive_scan(tmp, tb, cap_all, hit_all, n, stream_);
-    for (size_t k = 0; k < nsub; ++k) HIP_CHECK(hipMemcpyAsync(&hbase[k], hit_all + pieces[k].first, 8, hipMemcpyDeviceToHost, stream_));
   }
   if (nsub > 1 || by_piece) {
-    for (size_t k = 0; k <= nsub; ++k) {
-      const size_t at = k < nsub ? pieces[k].first : n;
-      if (src) { b1[k] = src->o1[at]; if (paired) b2[k] = src->o2[at]; }
-      else {
-        HIP_CHECK(hipMemcpyAsync(&b1[k], d_o1 + at, 8, hipMemcpyDeviceToHost, stream_));
-        if (paired) HIP_CHECK(hipMemcpyAsync(&b2[k], d_o2 + at, 8, hipMemcpyDeviceToHost, stream_));
+    if (src) {
+      for (size_t k = 0; k <= nsub; ++k) {
+        const size_t at = k < nsub ? pieces[k].first : n;
+        b1[k] = src->o1[at];
+        if (paired) b2[k] = src->o2[at];
       }
+    } else {
+      // one launch that stores the pieces' boundaries (and their hit-list offsets) into pinned host memory, one synchronisation
+      static_assert(kMaxSub + 1 <= 17, "PieceFirsts");
+      unsigned long long *pin = (unsigned long long *)pinned((2 + 3 * kMaxSub + 3 * (kMaxSub + 1)) * 8);
+      uint64_t *pb1 = (uint64_t *)(pin + 2 + 3 * kMaxSub), *pb2 = pb1 + (kMaxSub + 1), *ph = pb2 + (kMaxSub + 1);
+      PieceFirsts pf;
+      pf.n = (uint32_t)(nsub + 1);
+      for (size_t k = 0; k <= nsub; ++k) pf.at[k] = k < nsub ? pieces[k].first : n;
+      k_fetch_piece_scalars<<<1, 64, 0, stream_>>>(pf, d_o1, paired ? d_o2 : nullptr, hit_all, pb1, pb2, ph);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipStreamSynchronize(stream_));
+      for (size_t k = 0; k <= nsub; ++k) { b1[k] = pb1[k]; b2[k] = pb2[k]; if (k < nsub) hbase[k] = ph[k]; }
     }
-    if (!src) HIP_CHECK(hipStreamSynchronize(stream_));
     // one size for all pieces (the largest): the scratch buffers are then allocated once, not regrown under running kernels
     uint64_t m1 = 0, m2 = 0;
     for (size_t k = 0; k < nsub; ++k) { m1 = std::max(m1, b1[k + 1] - b1[k]); if (paired) m2 = std::max(m2, b2[k + 1] - b2[k]); }
@@ -1282,12 +1291,21 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       have_piece[k] = 1;
       return;
     }
-    auto one = [&](const uint8_t *hb, const uint64_t *ho, const uint8_t *db) {
+    auto one = [&](const uint8_t *hb, const uint64_t *hp, const uint64_t *ho, const uint8_t *db, uint64_t *packed) {
       const uint64_t a = ho[lo], b = ho[hi];
-      if (b > a) HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
+      if (b <= a) return;
+      if (hp) {
+        // packed blocks: into the search kernel's own buffer (a block shared with the neighbouring sub-batch arrives twice with the
+        // same bits) - or, with SDUST, into a staging copy (the search's blocks are then packed from the masked characters) - and
+        // unpacked, this sub-batch's characters only, for SDUST and the post stage
+        const uint64_t k0 = a >> 4, k1 = (b + 15) >> 4;
+        HIP_CHECK(hipMemcpyAsync(packed + k0, hp + k0, (k1 - k0) * 8, hipMemcpyHostToDevice, h2d_stream_));
+        k_unpack_reads<<<grid_for(k1 - k0), kBlock, 0, h2d_stream_>>>(packed + k0, k1 - k0, const_cast<uint8_t *>(db) + (k0 << 4), a - (k0 << 4), b - (k0 << 4));
+        HIP_CHECK(hipGetLastError());
+      } else HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
     };
-    one(src->b1, src->o1, d_b1);
-    if (paired) one(src->b2, src->o2, d_b2);
+    one(src->b1, src->p1, src->o1, d_b1, src->stage1 ? src->stage1 : packed1_);
+    if (paired) one(src->b2, src->p2, src->o2, d_b2, src->stage2 ? src->stage2 : packed2_);
     if (dust_ && !view_.prot.enabled) {
       // masked on a stream of its own, behind the piece's copy: the copy stream goes straight on with the next piece (the link
       // is what bounds this entry: 187 MB per piece at ~47 GB/s = 4 ms, the mask kernel 1.1-1.4 ms - on the copy stream
@@ -1304,6 +1322,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   auto pack_piece = [&](size_t k) {            // on the main stream, behind the copy of the piece
     if (!by_piece) return;
     HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
+    if (src && src->p1 && !src->stage1) return;       // the caller's packed blocks are in place (with SDUST they went to the staging copy and the masked characters are packed here)
     auto one = [&](uint64_t from, uint64_t to, const uint8_t *db, uint64_t total, uint64_t *packed) {
       const uint64_t b0 = from >> 4, b1x = (to + 15) >> 4;                // the blocks the piece touches (a block shared with the
       if (b1x > b0) k_pack_reads<<<grid_for(b1x - b0), kBlock, 0, stream_>>>(db + (b0 << 4), total - (b0 << 4), b1x - b0, packed + b0);   // next piece is packed again there)
@@ -1332,8 +1351,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipStreamSynchronize(stream_));              // (the compaction kernels may run on another stream)
   }
   // results / matches of piece k leave through the buffer pair of its parity while piece k+1 computes
-  auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, uint32_t *h_flag, hipStream_t st,
-                      const void *d_heavy = nullptr, unsigned long long *h_heavy = nullptr) {
+  auto copy_out = [&](size_t k, const cfr_result *d_res, const cfr_match *d_match, uint64_t extent, const void *d_flag, unsigned long long *h_flag, hipStream_t st) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     const int par = (int)(k & 1);
     if (compact) {                          // the narrow layout is made on the device; what is copied out are its arrays
@@ -1352,8 +1370,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, hipMemcpyDeviceToHost, copy_stream_));
       if (extent) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, hipMemcpyDeviceToHost, copy_stream_));
     }
-    if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 4, hipMemcpyDeviceToHost, copy_stream_));
-    if (d_heavy) HIP_CHECK(hipMemcpyAsync(h_heavy, d_heavy, 8, hipMemcpyDeviceToHost, copy_stream_));
+    if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 24, hipMemcpyDeviceToHost, copy_stream_));     // overflow flag + the two team counts
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   };
   auto out_buffers = [&](size_t k, uint64_t extent, cfr_result *&d_res, cfr_match *&d_match, hipStream_t st) {
@@ -1367,10 +1384,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   std::vector<size_t> todo;                 // pieces still to do
   for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
-    unsigned long long *pin = (unsigned long long *)pinned((2 + 2 * kMaxSub) * 8);    // one block: the pointers below stay valid
-    uint32_t *ovf = (uint32_t *)pin + 4;  // behind the two u64 totals
-    unsigned long long *heavy_h = pin + 2 + kMaxSub;   // reads k_tail_heavy folded, per sub-batch
-    for (size_t k = 0; k < kMaxSub; ++k) heavy_h[k] = 0;
+    unsigned long long *pin = (unsigned long long *)pinned((2 + 3 * kMaxSub + 3 * (kMaxSub + 1)) * 8);    // one block: the pointers below stay valid
+    // per sub-batch three words, fetched with ONE copy behind its post stage: pool-overflow flag, reads the small teams of
+    // k_tail_heavy folded, reads the large teams folded (= ctl[1..3] of the sub-batch's control block)
+    unsigned long long *pctl = pin + 2;
+    for (size_t k = 0; k < 3 * kMaxSub; ++k) pctl[k] = 0;
     if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
     const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
     for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
@@ -1378,7 +1396,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap_ * 8);
       for (size_t k : todo) {
         const size_t lo = pieces[k].first, cnt = pieces[k].second;
-        ovf[k] = 0;
+        pctl[3 * k] = 0;
         ev_ = evs_[k];
         if (attempt == 0) { bring_piece(k); pack_piece(k); }
         // the post stage runs on its own stream: it is a chain of dependent gathers per read (4 fabric requests per read,
@@ -1403,21 +1421,33 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         HIP_CHECK(hipMemsetAsync(ctl, 0, 32, ts));
         // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
         uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
+        uint64_t *heavy2 = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVYB1 : S_HEAVYB, std::max(sb, cnt) * 32) : nullptr;
         // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
         if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3);
         else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2);
+                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3);
         if (heavy) {
-          const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)(num_cus_ * (tail_overlap && tail_blocks_per_cu_ ? std::min(5, 2 * tail_blocks_per_cu_) : 5)));
-          if (paired) k_tail_heavy<4><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
-                                                                           (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
-          else k_tail_heavy<2><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_,
-                                                                    (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo);
+          // two tiers: teams of 8 lanes with 48 table entries, then - for the reads whose ids do not fit (hundreds of strains per
+          // species) - teams of 32 lanes with 192; what is left after that takes the single-lane form with pool scratch
+          const unsigned per_cu = (unsigned)(tail_overlap && tail_blocks_per_cu_ ? std::min(5, 2 * tail_blocks_per_cu_) : 5);
+          const unsigned hb = std::min<unsigned>((unsigned)((cnt + kTeamsPerBlock - 1) / kTeamsPerBlock), (unsigned)num_cus_ * per_cu);
+          const unsigned hb2 = std::min<unsigned>((unsigned)((cnt + kTeams2PerBlock - 1) / kTeams2PerBlock), (unsigned)num_cus_ * std::min(per_cu, 4u));
+          if (paired) {
+            k_tail_heavy<4, kTeam, kTeamSlots, kTeamsPerBlock, kTeamMaxEntries><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(
+                view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy2, ctl + 3);
+            k_tail_heavy<4, kTeam2, kTeam2Slots, kTeams2PerBlock, kTeam2MaxEntries><<<hb2, kTeam2 * kTeams2PerBlock, 0, ts>>>(
+                view_, d_o1 + lo, d_o2 + lo, sbuf.hit_off, sbuf.raw, heavy2, ctl + 3, pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, nullptr, nullptr);
+          } else {
+            k_tail_heavy<2, kTeam, kTeamSlots, kTeamsPerBlock, kTeamMaxEntries><<<hb, kTeam * kTeamsPerBlock, 0, ts>>>(
+                view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy, ctl + 2, pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy2, ctl + 3);
+            k_tail_heavy<2, kTeam2, kTeam2Slots, kTeams2PerBlock, kTeam2MaxEntries><<<hb2, kTeam2 * kTeams2PerBlock, 0, ts>>>(
+                view_, d_o1 + lo, nullptr, sbuf.hit_off, sbuf.raw, heavy2, ctl + 3, pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, nullptr, nullptr);
+          }
         }
         HIP_CHECK(hipGetLastError());
-        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &ovf[k], ts, heavy ? ctl + 2 : nullptr, &heavy_h[k]);
+        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &pctl[3 * k], ts);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
@@ -1427,11 +1457,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       if (attempt == 0) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
       if (attempt == 0) {                    // what the next call's schedule goes by: the share of reads with a team fold
         unsigned long long hv = 0;
-        for (size_t k = 0; k < nsub; ++k) hv += heavy_h[k];
+        for (size_t k = 0; k < nsub; ++k) hv += pctl[3 * k + 1] + pctl[3 * k + 2];     // (a read the small teams handed on counts twice: it is a threshold)
         heavy_frac_ = (double)hv / (double)n;
       }
       std::vector<size_t> again;
-      for (size_t k : todo) if (ovf[k]) again.push_back(k);              // the scratch pool ran dry in these
+      for (size_t k : todo) if (pctl[3 * k]) again.push_back(k);              // the scratch pool ran dry in these
       todo.swap(again);
       if (todo.empty() || pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP")) break;
       pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it
@@ -1474,6 +1504,20 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       HIP_CHECK(hipMemcpy(wide_idx_.data(), wide_side.idx, take * 4, hipMemcpyDeviceToHost));
       HIP_CHECK(hipMemcpy(wide_res_.data(), wide_side.res, take * sizeof(cfr_result), hipMemcpyDeviceToHost));
       HIP_CHECK(hipMemcpy(wide_match_.data(), wide_side.match, take * stride * sizeof(cfr_match), hipMemcpyDeviceToHost));
+      // A sub-batch that was computed again (its scratch pool ran dry: a second attempt, or the multi-kernel form) appended its
+      // flagged reads again; the entries stand in the order they were made, so the LAST one of a read is the one that belongs to
+      // the results the caller got.  (match_begin points into wide_match_, which stays as it is.)
+      if (cntw <= kWideSideCap) {
+        std::vector<uint32_t> order(take);
+        for (size_t j = 0; j < take; ++j) order[j] = (uint32_t)j;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return wide_idx_[a] < wide_idx_[b]; });
+        std::vector<uint32_t> idx2;
+        std::vector<cfr_result> res2;
+        for (size_t j = 0; j < take; ++j) if (j + 1 == take || wide_idx_[order[j + 1]] != wide_idx_[order[j]]) { idx2.push_back(wide_idx_[order[j]]); res2.push_back(wide_res_[order[j]]); }
+        wide_idx_.swap(idx2);
+        wide_res_.swap(res2);
+        wide_total_ = wide_idx_.size();
+      }
     }
   }
   if (!repeated) {                          // wall time of the device work: first event of the first piece to the last of the last
@@ -1509,6 +1553,53 @@ void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uin
   }
   Staged st = stage_inputs(b1, o1, b2, o2, n);
   classify_device(st.b1, st.o1, st.b2, st.o2, n, st.t1, st.t2, results, matches, match_cap, match_extent);
+}
+
+void DeviceIndex::classify_host_packed(const uint64_t *p1, const uint64_t *o1, const uint64_t *p2, const uint64_t *o2, size_t n,
+                                       cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent) {
+  HIP_CHECK(hipSetDevice(device_));
+  if (n == 0) { if (match_extent) *match_extent = 0; last_stats = cfr_batch_stats{}; return; }
+  const uint64_t t1 = o1[n], t2 = p2 ? o2[n] : 0;
+  uint8_t *d_b1 = (uint8_t *)scratch(S_IN_B1, t1 + 32);
+  uint64_t *d_o1 = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
+  uint8_t *d_b2 = nullptr;
+  uint64_t *d_o2 = nullptr;
+  if (p2) {
+    d_b2 = (uint8_t *)scratch(S_IN_B2, t2 + 32);
+    d_o2 = (uint64_t *)scratch(S_IN_O2, (n + 1) * 8);
+  }
+  static const bool stream_inputs = !(dbg_env("CFR_STREAM_INPUTS") && atoi(dbg_env("CFR_STREAM_INPUTS")) == 0);
+  if (stream_inputs && !search_v1_ && view_.max_result > 0 && one_launch_ready()) {
+    // streamed like classify_host: the offsets up front, the blocks of sub-batch k + 1 under the kernels of sub-batch k
+    HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
+    if (p2) HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, h2d_stream_));
+    HostSrc src{nullptr, o1, nullptr, o2};
+    src.p1 = p1;
+    src.p2 = p2;
+    if (dust_ && !view_.prot.enabled) {
+      src.stage1 = (uint64_t *)scratch(S_P0, ((t1 + 15) / 16 + 1) * 8);
+      if (p2) src.stage2 = (uint64_t *)scratch(S_P1, ((t2 + 15) / 16 + 1) * 8);
+    }
+    classify_device(d_b1, d_o1, d_b2, d_o2, n, t1, t2, results, matches, match_cap, match_extent, &src);
+    return;
+  }
+  // the other forms of the path (protein index, row-space matches, kernel v1): the whole batch is unpacked first
+  auto whole = [&](const uint64_t *hp, uint8_t *db, uint64_t total, size_t slot) {
+    const uint64_t nb = (total + 15) >> 4;
+    uint64_t *tmp = (uint64_t *)scratch(slot, (nb + 1) * 8);
+    if (nb) {
+      HIP_CHECK(hipMemcpyAsync(tmp, hp, nb * 8, hipMemcpyHostToDevice, stream_));
+      k_unpack_reads<<<grid_for(nb), kBlock, 0, stream_>>>(tmp, nb, db, 0, total);
+      HIP_CHECK(hipGetLastError());
+    }
+  };
+  whole(p1, d_b1, t1, S_P0);
+  HIP_CHECK(hipMemcpyAsync(d_o1, o1, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  if (p2) {
+    whole(p2, d_b2, t2, S_P1);
+    HIP_CHECK(hipMemcpyAsync(d_o2, o2, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  }
+  classify_device(d_b1, d_o1, d_b2, d_o2, n, t1, t2, results, matches, match_cap, match_extent);
 }
 
 void *DeviceIndex::pinned(size_t bytes) {

@@ -125,7 +125,8 @@ void *host_alloc_pinned(size_t bytes);
 void host_free_pinned(void *p);
 
 // host buffers of a batch whose bases are streamed to the device sub-batch by sub-batch (DeviceIndex::classify_host)
-struct HostSrc { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2; };
+struct HostSrc { const uint8_t *b1; const uint64_t *o1; const uint8_t *b2; const uint64_t *o2;
+                 const uint64_t *p1 = nullptr, *p2 = nullptr; uint64_t *stage1 = nullptr, *stage2 = nullptr; };      // p1 / p2: the bases in packed form (k_pack_reads' blocks) instead of b1 / b2; stage: where they land on the device when they are not the search's own blocks
 
 class DeviceIndex {
  public:
@@ -164,6 +165,9 @@ class DeviceIndex {
                        size_t *match_extent, const struct HostSrc *src = nullptr, bool compact = false);   // compact: results / matches are cfr_result_compact / cfr_match_compact arrays
   void classify_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2, size_t n,
                      cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent);
+  // the same with the bases as packed blocks (cfr_classify_batch_packed): half the bytes over PCIe, unpacked on the device
+  void classify_host_packed(const uint64_t *packed1, const uint64_t *offs1, const uint64_t *packed2, const uint64_t *offs2, size_t n,
+                            cfr_result *results, cfr_match *matches, size_t match_cap, size_t *match_extent);
 
   // convenience: host buffers -> device, then run_batch
   void run_batch_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2,

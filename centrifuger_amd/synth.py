@@ -35,7 +35,10 @@ class Genomes:
 
 
 def make_genomes(n_species: int, n_strains: int, genome_len: int, seed: int,
-                 divergence_step: float = 0.01, species_per_genus: int = 2) -> Genomes:
+                 divergence_step: float = 0.01, species_per_genus: int = 2, model: str = "star") -> Genomes:
+    """model "star": strain k = the species base with k x divergence_step i.i.d. substitutions (cfg2's text).  model "tree": strain k
+    descends from strain (k - 1) // 2 with divergence_step NEW substitutions per edge - a binary phylogeny, so that close relatives
+    are one or two steps apart and the far ends of a 200-strain species 2 log2(200) steps (what a redundant database looks like)."""
     rng = np.random.default_rng(seed)
     names, taxids, seqs = [], [], []
     nodes = [(1, 1, "no rank"), (2, 1, "superkingdom")]
@@ -58,11 +61,21 @@ def make_genomes(n_species: int, n_strains: int, genome_len: int, seed: int,
             next_tid += 1
             nodes.append((st_tid, sp_tid, "strain"))
             tax_names.append((st_tid, f"species{sp} strain{k}"))
-            g = base.copy()
-            if k > 0:
-                nmut = int(genome_len * divergence_step * k)
-                pos = rng.integers(0, genome_len, size=nmut)
-                g[pos] = (g[pos] + rng.integers(1, 4, size=nmut, dtype=np.uint8)) & 3
+            if model == "tree":
+                g = base.copy() if k == 0 else codes[(k - 1) // 2].copy()
+                if k > 0:
+                    nmut = int(genome_len * divergence_step)
+                    pos = rng.integers(0, genome_len, size=nmut)
+                    g[pos] = (g[pos] + rng.integers(1, 4, size=nmut, dtype=np.uint8)) & 3
+                if k == 0:
+                    codes = []
+                codes.append(g)
+            else:
+                g = base.copy()
+                if k > 0:
+                    nmut = int(genome_len * divergence_step * k)
+                    pos = rng.integers(0, genome_len, size=nmut)
+                    g[pos] = (g[pos] + rng.integers(1, 4, size=nmut, dtype=np.uint8)) & 3
             names.append(f"SEQ_{sp:04d}_{k}.1")
             taxids.append(st_tid)
             seqs.append(ACGT[g])

@@ -180,6 +180,21 @@ cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uin
                               const uint8_t *bases2, const uint64_t *offsets2, size_t n,
                               cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
 
+/* The same call with the bases in PACKED form: block b (one uint64_t) holds the 16 characters [16 b, 16 b + 16) of the flat buffer
+ * the offsets refer to - character j of the block as a 2-bit code (A 0, C 1, G 2, T 3) at bits 2j..2j+1, and bit 32 + j set when
+ * the character is one of the upper-case letters A, C, G, T (anything else - N, lower case, IUPAC codes, bytes past the end of the
+ * buffer - has the bit clear and code bits that do not matter).  (total + 15) / 16 blocks per buffer.  Half the bytes of the ASCII
+ * form cross PCIe (the ASCII entry is bound by its 1 byte per base: 3.2e8 reads/s of 150 bp from pinned memory); results are those of
+ * cfr_classify_batch on the same reads, SDUST on the device included when it is switched on - nothing on the path tells two
+ * non-symbols apart (a non-symbol ends a match, FMIndex.hpp:396-401; is SDUST's fifth code; reverse-complements to 'N',
+ * Classifier.hpp:846-856).  Nucleotide indexes only: the translated search of a protein index does tell them apart (DnaToAa,
+ * Classifier.hpp:131-241), so the call returns CFR_ERR_ARG there.  cfr_pack_reads makes the blocks from an ASCII buffer on `threads` host threads (a parser can also
+ * emit them directly).  The reference reads ASCII through kseq (ReadFiles.hpp:337); there is no packed form there. */
+cfr_status cfr_pack_reads(const uint8_t *bases, uint64_t total, int threads, uint64_t *packed);
+cfr_status cfr_classify_batch_packed(cfr_dev_index *d, const uint64_t *packed1, const uint64_t *offsets1,
+                                     const uint64_t *packed2, const uint64_t *offsets2, size_t n,
+                                     cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
+
 /* Asynchronous form of cfr_classify_batch.  The reference overlaps reading, classification and output of consecutive batches
  * (CentrifugerClass.cpp:776-800: the next batch is read while the threads classify this one); a caller of this library gets the
  * same by submitting batch k+1 before it waits for batch k:

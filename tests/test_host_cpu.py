@@ -498,3 +498,30 @@ def test_digest_is_stable_and_tells_indexes_apart():
     assert len(set(first)) == len(first)
     for _ in range(20):
         assert [capi.Index(p).digest() for p in names] == first
+
+
+def test_pack_reads_equals_the_definition():
+    """cfr_pack_reads: block b = characters [16 b, 16 b + 16): 2-bit codes (A 0, C 1, G 2, T 3) at bits 2j, validity of upper-case ACGT at bit
+    32 + j, nothing else set; bytes past the end are not symbols; one thread and many give the same blocks."""
+    rng = np.random.default_rng(3)
+    for total in (0, 1, 15, 16, 17, 31, 33, 1000, 70001):
+        b = rng.choice(np.frombuffer(b"ACGTNacgtRY-\x00\xff", dtype=np.uint8), size=total, p=[.22, .22, .22, .22] + [.12 / 10] * 10)
+        got = capi.pack_reads(b, threads=1)
+        assert np.array_equal(got, capi.pack_reads(b, threads=7))
+        nblk = (total + 15) // 16
+        assert len(got) == nblk
+        pad = np.zeros(nblk * 16, dtype=np.uint8)
+        pad[:total] = b
+        code = np.full(256, 0, dtype=np.uint64)
+        valid = np.zeros(256, dtype=np.uint64)
+        for k, ch in enumerate(b"ACGT"):
+            code[ch] = k
+            valid[ch] = 1
+        v = pad.reshape(nblk, 16)
+        want = np.zeros(nblk, dtype=np.uint64)
+        for j in range(16):
+            want |= valid[v[:, j]] << np.uint64(32 + j)
+        assert np.array_equal(got >> np.uint64(32), want >> np.uint64(32))
+        for j in range(16):        # code bits only where the character is a symbol
+            ok = valid[v[:, j]] == 1
+            assert np.array_equal(((got >> np.uint64(2 * j)) & np.uint64(3))[ok], code[v[:, j]][ok])
