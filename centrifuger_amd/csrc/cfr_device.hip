@@ -121,7 +121,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   num_cus_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char *e = dbg_env("CFR_SEARCH_V1")) search_v1_ = atoi(e) != 0;
   if (const char *e = dbg_env("CFR_FUSED_TAIL")) fused_tail_ = atoi(e) != 0;
-  if (const char *e = dbg_env("CFR_BLOCKS_PER_CU")) blocks_per_cu_ = std::max(1, atoi(e));
+  if (const char *e = dbg_env("CFR_BLOCKS_PER_CU")) { blocks_per_cu_ = std::max(1, atoi(e)); blocks_forced_ = true; }
   if (const char *e = dbg_env("CFR_TAPER_FLOOR")) taper_floor_ = strtoull(e, nullptr, 10);
   wide_ = h.n >= 0xfffffff0ull;
   if (const char *e = dbg_env("CFR_FORCE_WIDE")) wide_ = wide_ || atoi(e) != 0;      // test hook: the n >= 2^32 code path on a small index
@@ -844,6 +844,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     // persistent grid: every lane walks chains gid, gid + T, ... (T = resident lanes), see k_search_chains_v2
     // resident blocks only: a block that had to wait for a slot would start its share of the chains late
     int resident = blocks_per_cu_;
+    if (overlap_now_ && !blocks_forced_) resident = std::min(resident, 4);      // leave the post stage of the previous sub-batch its wave slots
     {
       int occ = 0;
       const bool wide_k = wide_;
@@ -870,6 +871,9 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     // few chains per lane (long reads): chains are handed out dynamically (DYN), one atomic per chain
     bool dyn = nchains < 8ull * blocks * kBlock && (total1 + total2) / std::max<size_t>(1, nchains) >= 500;    // (per chain: half the mean read)
     if (const char *e = dbg_env("CFR_SEARCH_DYN")) dyn = atoi(e) != 0;
+    // short reads handed out dynamically (so that the post stage of the previous sub-batch can run beside this search: a block that
+    // starts late then simply takes fewer chains): eight chains per draw; long reads: one
+    const uint32_t dyn_chunk = dyn && (total1 + total2) / std::max<size_t>(1, nchains) < 500 ? 8u : 1u;
     unsigned long long *d_ctr = nullptr;
     if (dyn) {
       d_ctr = (unsigned long long *)scratch(S_P5, 16 * 8) + 15;
@@ -878,7 +882,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const uint64_t *p2 = paired ? packed2_ : nullptr, *o2 = paired ? d_o2 : nullptr;
     const uint64_t nb2 = paired ? nblk2_ : 0;
 #define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
-    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr)
+    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
     if (dbg_env("CFR_SEARCH_PROF") && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
@@ -1334,7 +1338,12 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // the post stage beside the next sub-batch's search: pays when the post stage is long (reads over families of strains:
   // 20-strain workload 2.97e8 -> 3.3e8 reads/s) and costs when it is short (cfg2: the search runs 20 % slower with anything
   // beside it, 6.8e8 -> 6.3e8).  The share of reads the last call folded by teams decides (CFR_TAIL_STREAM=0/1 forces it).
-  const bool tail_overlap = tail_overlap_mode_ >= 0 ? tail_overlap_mode_ != 0 : heavy_frac_ > 0.2;
+  // Round 4 measured it again (tools/dbg/ab_dyn_tail.sh, profiles/r4f_ab_tail_overlap.txt): with the search held to 4 blocks per CU
+  // the post stage beside it wins on every workload - cfg2 14.16 -> 13.19 ms per step (search 9.97 -> 10.95 ms, the 2.8 ms of post
+  // stage gone), pairs 29.3 -> 27.9 - where round 3 had seen a loss with 5 blocks per CU and no room left for the post stage's
+  // waves.  So it is the default whenever a batch has more than one sub-batch (CFR_TAIL_STREAM=0/1 forces it).
+  const bool tail_overlap = tail_overlap_mode_ >= 0 ? tail_overlap_mode_ != 0 : true;
+  overlap_now_ = tail_overlap && one_launch && nsub > 1;
   if (src && !one_launch) throw HipError{"streamed host inputs need the one-launch post stage", -4};
   bring_piece(0);
 

@@ -234,6 +234,7 @@ class DeviceIndex {
   hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr, tail_stream_ = nullptr, dust_stream_ = nullptr;
   hipEvent_t search_done_[2] = {};
   int tail_overlap_mode_ = -1;           // the post stage of a sub-batch beside the search of the next one: -1 = by heavy_frac_, 0 / 1
+  bool overlap_now_ = false, blocks_forced_ = false;   // this call runs the post stage beside the next search; CFR_BLOCKS_PER_CU was given
   double heavy_frac_ = 0.0;              // share of the last call's reads that k_tail_heavy folded
   int tail_blocks_per_cu_ = 0;           // blocks per CU of the post stage when it runs beside a search (0: one lane per read)
   hipEvent_t tail_done_[2] = {}, copy_done_[2] = {}, h2d_done_[kMaxSub] = {}, copied_[kMaxSub] = {};

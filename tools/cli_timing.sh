@@ -24,6 +24,20 @@ if [ -x oracle/_ref/centrifuger ]; then
   ( time oracle/_ref/centrifuger -x $idx -u $big -t 64 > /tmp/ref_big.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
   md5sum /tmp/ref_big.tsv | tee -a $out
 fi
+# ---- compressed input: the same 10 M reads as fastq.gz (one deflate stream: the inflate thread bounds the run; the reference reads it through kseq + gzread)
+fq=/tmp/big10m.fq.gz
+awk 'NR % 2 == 1 { print "@" substr($0, 2) } NR % 2 == 0 { print; print "+"; q = $0; gsub(/./, "I", q); print q }' $big | gzip -1 > $fq
+echo "== 10 M reads as fastq.gz ($(du -h $fq | cut -f1)), -t 64" | tee -a $out
+( time CFR_CLI_TIMING=1 centrifuger_amd/bin/centrifuger -x $idx -u $fq -t 64 > /tmp/cli_gz.tsv ) 2>&1 | grep -E "timing|real" | tee -a $out
+md5sum /tmp/cli_gz.tsv | tee -a $out
+fq2=/tmp/sample2m.fq.gz
+awk 'NR % 2 == 1 { print "@" substr($0, 2) } NR % 2 == 0 { print; print "+"; q = $0; gsub(/./, "I", q); print q }' $fa | gzip -1 > $fq2
+if [ -x oracle/_ref/centrifuger ]; then
+  echo "== 2 M reads as fastq.gz: reference -t 64 vs this command line" | tee -a $out
+  ( time oracle/_ref/centrifuger -x $idx -u $fq2 -t 64 > /tmp/ref_gz.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
+  ( time centrifuger_amd/bin/centrifuger -x $idx -u $fq2 -t 64 > /tmp/own_gz.tsv 2>/dev/null ) 2>&1 | grep real | tee -a $out
+  md5sum /tmp/ref_gz.tsv /tmp/own_gz.tsv | tee -a $out
+fi
 # ---- pairs: 10 M pairs (-1/-2, -k 5) and the same as one interleaved file; plain files are cut at equal record numbers and parsed in pieces
 python bench.py --mode pe --steps 1 --warmup 1 --no-pmc --no-extra-configs > gpurun_out/cli_bench_pe.json 2> gpurun_out/cli_bench_pe.err
 f1=$(ls /tmp/cfr_bench/*/sample_0.fa 2>/dev/null | head -1); f2=${f1%.fa}_2.fa

@@ -14,10 +14,10 @@ O=$ROOT/gpurun_out
 mkdir -p $O
 cd $ROOT
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.log
-# kernel trace of the timed steps (no CPU baseline leg, no child passes: they only add host time)
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $ROOT/bench.py --no-cpu-baseline --no-pmc --no-extra-configs > $O/${TAG}_trace.json 2> $O/${TAG}_trace.log )
+# kernel trace of the plain entry alone: warm-up + timed steps and nothing else in the process, so that every dispatch divides by the steps
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $ROOT/bench.py --inner --no-cpu-baseline --no-pmc --no-extra-configs --steps 10 --warmup 2 > $O/${TAG}_trace.json 2> $O/${TAG}_trace.log )
 db=$(find $O/${TAG}_trace -name "*.db" | head -1)
-[ -n "$db" ] && python tools/rocpd_summary.py $db $O/${TAG}_kernel_trace_stats.txt
+[ -n "$db" ] && python tools/trace_reconcile.py $db $O/${TAG}_trace.json $O/${TAG}_kernel_trace_stats.txt > /dev/null
 rm -rf $O/${TAG}_trace
 # PMC passes: one 2 M-read launch per kernel (a single sub-batch, so per-launch counters divide by 2 M reads)
 CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0 tools/pmc_passes.sh $O/${TAG}_pmc --no-pmc --no-extra-configs > $O/${TAG}_pmc.log 2>&1
