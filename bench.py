@@ -1147,6 +1147,12 @@ def main():
                          "note": "fabric read requests per second over tools/gather_bench's ceiling for dependent random gathers at this footprint"},
               "note": "achieved = bytes the kernel moves over the fabric (PMC TCC_EA0_RDREQ x 128 B calibrated + WRITE_SIZE, one 2 M-read launch "
                       "under rocprofv3 --pmc, scaled per read) / kernel time of the timed steps (HIP events on the library stream)"})
+          if pmc.get("kernel_ms_profiled"):
+              # the same traffic over the kernel's duration when it has the chip to itself (the one-launch counter pass: no post stage
+              # of a previous sub-batch beside it) - `frac` is taken over the time it needs inside the step, sharing the chip with that post stage
+              alone_ms = pmc["kernel_ms_profiled"] / pmc["reads"] * args.reads
+              roof["frac_kernel_alone"] = traffic / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+              roof["kernel_ms_alone"] = alone_ms
           roof["l2_hit"] = pmc.get("l2_hit")
           roof["frac_counter_traffic"] = roof["frac"]
           if pmc.get("prof"):

@@ -883,7 +883,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const uint64_t nb2 = paired ? nblk2_ : 0;
 #define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
     k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
-    if (dbg_env("CFR_SEARCH_PROF") && !paired) {
+    if (dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
       HIP_CHECK(hipMemsetAsync(d_prof, 0, 15 * 8, stream_));
