@@ -1430,13 +1430,17 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         HIP_CHECK(hipMemsetAsync(ctl, 0, 32, ts));
         // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
         uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
+        // reads with more located rows than this go straight to the large teams (distinct ids <= rows: 48 fit the small teams' table; up to
+        // 64 rows most reads still do - the same strains in every hit - and the few that do not are handed on): 200 strains per species
+        // 96 -> 73 ms per step, 20 strains unchanged (profiles/r4n_strains_traces.txt).  0 = every read starts with the small teams
+        static const uint32_t direct_rows = dbg_env("CFR_HEAVY_DIRECT_ROWS") ? (uint32_t)atoi(dbg_env("CFR_HEAVY_DIRECT_ROWS")) : 64u;
         uint64_t *heavy2 = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVYB1 : S_HEAVYB, std::max(sb, cnt) * 32) : nullptr;
         // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
         if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3);
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
         else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3);
+                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
         if (heavy) {
           // two tiers: teams of 8 lanes with 48 table entries, then - for the reads whose ids do not fit (hundreds of strains per
           // species) - teams of 32 lanes with 192; what is left after that takes the single-lane form with pool scratch
