@@ -1231,7 +1231,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     if (d_b2) d_b2 = (const uint8_t *)scratch(S_DUSTTMP2, total2 + 16);
   }
   const bool by_piece = src != nullptr || dust_pieces;             // the bases of a sub-batch arrive (and are packed) right before its search
-  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece);
+  // resident reads in several sub-batches: each sub-batch is packed right in front of its own search (test hook CFR_PACK_PIECES=1) instead of
+  // the whole batch up front - the packing of sub-batch k + 1 then runs while the post stage of k - 1 still has the other stream
+  static const bool pack_pieces_on = dbg_env("CFR_PACK_PIECES") && atoi(dbg_env("CFR_PACK_PIECES")) != 0;
+  const bool pack_late = pack_pieces_on && !by_piece && !search_v1_;
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece && !pack_late);
   size_t sb = 0;
   const auto pieces = cut_pieces(n, stride > 0, sb, total1 + total2);
   const size_t nsub = pieces.size();
@@ -1279,6 +1283,12 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     for (size_t k = 0; k < nsub; ++k) { m1 = std::max(m1, b1[k + 1] - b1[k]); if (paired) m2 = std::max(m2, b2[k + 1] - b2[k]); }
     for (size_t k = 0; k < nsub; ++k) { pt1[k] = m1; pt2[k] = m2; }
   }
+  const bool pack_late_now = pack_late && nsub > 1;
+  if (pack_late && !pack_late_now) {           // a single sub-batch: pack it now after all
+    auto whole = [&](const uint8_t *db, uint64_t total, uint64_t nblk, uint64_t *packed) { if (nblk) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(db, total, nblk, packed); };
+    whole(d_b1, total1, nblk1_, packed1_);
+    if (paired) whole(d_b2, total2, nblk2_, packed2_);
+  }
   const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
@@ -1324,8 +1334,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     have_piece[k] = 1;
   };
   auto pack_piece = [&](size_t k) {            // on the main stream, behind the copy of the piece
-    if (!by_piece) return;
-    HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
+    if (!by_piece && !pack_late_now) return;
+    if (by_piece) HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
     if (src && src->p1 && !src->stage1) return;       // the caller's packed blocks are in place (with SDUST they went to the staging copy and the masked characters are packed here)
     auto one = [&](uint64_t from, uint64_t to, const uint8_t *db, uint64_t total, uint64_t *packed) {
       const uint64_t b0 = from >> 4, b1x = (to + 15) >> 4;                // the blocks the piece touches (a block shared with the
