@@ -49,7 +49,8 @@ def world(tmp_path_factory):
     reads = synth.make_reads(g, N_READS, READ_LEN, seed=77, sub_rate=0.01, n_rate=0.001)
     r1, r2 = synth.make_pairs(g, 200_000, 125, seed=78)
     longs = synth.make_long_reads(g, 3000, 2000, 12000, seed=79)
-    return {"prefix": prefix, "reads": reads, "pairs": (r1, r2), "long": longs, "exact70k": np.ascontiguousarray(g.seqs[0][1000:71000])}
+    return {"prefix": prefix, "reads": reads, "pairs": (r1, r2), "long": longs, "exact70k": np.ascontiguousarray(g.seqs[0][1000:71000]),
+            "exact2m": np.concatenate([np.frombuffer(bytes(g.seqs[0]), dtype=np.uint8), np.frombuffer(bytes(g.seqs[1]), dtype=np.uint8)])}
 
 
 def _open(prefix, k, env=None):
@@ -386,6 +387,34 @@ def test_very_long_read_among_short_ones(world):
         for i in range(51):
             assert idx.format_tsv("r", res[i], mat) == orc.format("r", ores[i]), (k, i)
         assert res[25]["query_length"] == len(big) and res[25]["n_match"] > 0
+        orc.close()
+        dev.close()
+
+
+def test_exact_match_of_two_million_characters(world):
+    """A read that IS two neighbouring genomes of the text (2 Mbp, exact; forward and reverse-complemented) among short reads: the search
+    finishes on the text with more than 2^20 characters matched since it entered it - what a text-space hit stores in its row field
+    (the field had 20 bits; it has 27 now and a search only enters the text when what is left of it fits) - and the located
+    positions decide the sequence ids.  TSV lines against the oracle."""
+    rs = world["reads"]
+    short_b, short_o = rs.bases[:150 * 20], rs.offsets[:21]
+    big = world["exact2m"]
+    assert len(big) == 2_000_000
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, c in zip(b"ACGT", b"TGCA"):
+        comp[a] = c
+    rc = comp[big[::-1]]
+    b = np.concatenate([short_b[:150 * 10], big, short_b[150 * 10:], rc])
+    o = np.concatenate([short_o[:11], [short_o[10] + len(big)], short_o[11:] + len(big), [short_o[20] + 2 * len(big)]]).astype(np.uint64)
+    assert int(o[-1]) == len(b) and len(o) == 23
+    for k in (1, 5):
+        idx, dev = _open(world["prefix"], k)
+        res, mat = dev.classify(b, o)
+        orc = ora.OracleIndex(world["prefix"], max_result=k)
+        ores = orc.classify(b, o, threads=2)
+        for i in range(22):
+            assert idx.format_tsv("r", res[i], mat) == orc.format("r", ores[i]), (k, i)
+        assert res[10]["hit_length"] >= 1_999_000 and res[21]["hit_length"] >= 1_999_000
         orc.close()
         dev.close()
 
