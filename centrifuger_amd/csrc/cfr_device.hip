@@ -1234,7 +1234,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // resident reads in several sub-batches: each sub-batch is packed right in front of its own search (test hook CFR_PACK_PIECES=1) instead of
   // the whole batch up front - the packing of sub-batch k + 1 then runs while the post stage of k - 1 still has the other stream
   static const bool pack_pieces_on = dbg_env("CFR_PACK_PIECES") && atoi(dbg_env("CFR_PACK_PIECES")) != 0;
-  const bool pack_late = pack_pieces_on && !by_piece && !search_v1_;
+  // test hook CFR_PACK_SPLIT=1: the first sub-batch packed in front of its search, the rest in one launch on the (otherwise idle) upload
+  // stream beside that search.  Measured (profiles/r4x_ab_pack_split.txt): 13.2-13.3 against 13.05 ms per step, pairs 29.0 against 28.2 -
+  // the 0.4 ms of packing it takes out of the front come back as a slower first search; everything up front on the main stream stays
+  static const bool pack_split_on = dbg_env("CFR_PACK_SPLIT") && atoi(dbg_env("CFR_PACK_SPLIT")) != 0;
+  const bool pack_late = (pack_pieces_on || pack_split_on) && !by_piece && !search_v1_;
   if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece && !pack_late);
   size_t sb = 0;
   const auto pieces = cut_pieces(n, stride > 0, sb, total1 + total2);
@@ -1283,11 +1287,27 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     for (size_t k = 0; k < nsub; ++k) { m1 = std::max(m1, b1[k + 1] - b1[k]); if (paired) m2 = std::max(m2, b2[k + 1] - b2[k]); }
     for (size_t k = 0; k < nsub; ++k) { pt1[k] = m1; pt2[k] = m2; }
   }
-  const bool pack_late_now = pack_late && nsub > 1;
-  if (pack_late && !pack_late_now) {           // a single sub-batch: pack it now after all
-    auto whole = [&](const uint8_t *db, uint64_t total, uint64_t nblk, uint64_t *packed) { if (nblk) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(db, total, nblk, packed); };
-    whole(d_b1, total1, nblk1_, packed1_);
-    if (paired) whole(d_b2, total2, nblk2_, packed2_);
+  const bool pack_late_now = pack_late && pack_pieces_on && nsub > 1;
+  bool pack_rest_pending = false;
+  if (pack_late && !pack_late_now) {
+    // blocks [from, to) of a buffer on stream st
+    auto part = [&](const uint8_t *db, uint64_t total, uint64_t *packed, uint64_t from, uint64_t to, hipStream_t st) {
+      if (to > from) k_pack_reads<<<grid_for(to - from), kBlock, 0, st>>>(db + (from << 4), total - (from << 4), to - from, packed + from);
+    };
+    if (nsub > 1) {
+      const uint64_t c1 = std::min(nblk1_, (b1[1] + 15) >> 4), c2 = paired ? std::min(nblk2_, (b2[1] + 15) >> 4) : 0;
+      part(d_b1, total1, packed1_, 0, c1, stream_);
+      if (paired) part(d_b2, total2, packed2_, 0, c2, stream_);
+      // (the block the first two sub-batches share is packed by both launches, with the same bits)
+      part(d_b1, total1, packed1_, b1[1] >> 4, nblk1_, h2d_stream_);
+      if (paired) part(d_b2, total2, packed2_, b2[1] >> 4, nblk2_, h2d_stream_);
+      HIP_CHECK(hipEventRecord(copied_[0], h2d_stream_));
+      pack_rest_pending = true;
+    } else {                                   // a single sub-batch: pack it now after all
+      part(d_b1, total1, packed1_, 0, nblk1_, stream_);
+      if (paired) part(d_b2, total2, packed2_, 0, nblk2_, stream_);
+    }
+    HIP_CHECK(hipGetLastError());
   }
   const bool fused = fused_tail_ && locate_direct();     // k_tail locates rows itself (memo / suffix array + step function / virtual rows)
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
@@ -1424,6 +1444,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const int par = tail_overlap ? (int)(k & 1) : 0;
         hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
         if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
+        if (pack_rest_pending && k >= 1) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[0], 0)); pack_rest_pending = false; }
         pre_hit_off_ = hit_all ? hit_all + lo : nullptr;
         pre_hit_base_ = hit_all ? hbase[k] : 0;
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], par);
@@ -1493,6 +1514,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const bool repeated = one_launch && !todo.empty();
 
   // ---- multi-kernel form: search, adjust/select, (compact, rows, locate,) tail; one or two 8-byte host syncs per piece
+  if (pack_rest_pending) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[0], 0)); pack_rest_pending = false; }
   for (size_t k : todo) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     ev_ = evs_[k];
