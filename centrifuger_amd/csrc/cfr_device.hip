@@ -935,12 +935,40 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   uint8_t *codes1 = (uint8_t *)scratch(S_PCODES1, 2 * prot_total1_ + 56 * (prot_reads_ + 1) + 128);
   uint8_t *codes2 = paired ? (uint8_t *)scratch(S_PCODES2, 2 * prot_total2_ + 56 * (prot_reads_ + 1) + 128) : nullptr;
   const unsigned tr_grid = std::min<unsigned>((unsigned)((n * (paired ? 2 : 1) + 3) / 4), (unsigned)(num_cus_ * 8));   // a wave per read and mate, grid-stride
+  // the searches: lanes as state machines on a resident grid (k_search_prot_sm) when the image has the 128-byte records and the tables'
+  // keys fit the twelve codes a lane looks at; CFR_PROT_SM=0: one chain per lane from start to end (k_search_prot), the same hits
+  static const bool want_sm = !(dbg_env("CFR_PROT_SM") && atoi(dbg_env("CFR_PROT_SM")) == 0);
+  const bool sm = want_sm && view_.prot.rec != nullptr && view_.ftabx_width <= 12 && view_.ftab_width <= 12 && nchains < 0xfc000000ull;
+  unsigned sm_blocks = 0;
+  static const int sm_minb = dbg_env("CFR_PROT_SM_MINB") ? atoi(dbg_env("CFR_PROT_SM_MINB")) : 1;
+  static const int minb = dbg_env("CFR_PROT_MINB") ? atoi(dbg_env("CFR_PROT_MINB")) : 1;    // k_search_prot's register budget: 8 blocks per CU = 64 VGPRs (a few spills), 6 = 80
+  if (sm) {
+    static int occ1 = 0, occ2 = 0;
+    int &occ = paired ? occ2 : occ1;
+    if (occ == 0) {
+      hipError_t e = paired ? (sm_minb == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<2, 6>, kBlock, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<2, 1>, kBlock, 0))
+                            : (sm_minb == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<1, 6>, kBlock, 0)
+                                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<1, 1>, kBlock, 0));
+      if (e != hipSuccess || occ <= 0) occ = 4;
+      if (dbg_env("CFR_PROT_BLOCKS")) occ = std::max(1, atoi(dbg_env("CFR_PROT_BLOCKS")));
+    }
+    sm_blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * occ));
+  }
   if (paired) {
     k_translate_prot<2><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2, read0);
-    k_search_prot<2><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    if (sm && sm_minb == 6) k_search_prot_sm<2, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    else if (sm) k_search_prot_sm<2, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    else if (minb == 8) k_search_prot<2, 8><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    else if (minb == 6) k_search_prot<2, 6><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    else k_search_prot<2, 1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
   } else {
     k_translate_prot<1><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr, read0);
-    k_search_prot<1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    if (sm && sm_minb == 6) k_search_prot_sm<1, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    else if (sm) k_search_prot_sm<1, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    else if (minb == 8) k_search_prot<1, 8><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    else if (minb == 6) k_search_prot<1, 6><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    else k_search_prot<1, 1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
   }
   HIP_CHECK(hipGetLastError());
   HIP_CHECK(hipEventRecord(ev_[2], stream_));
@@ -1048,7 +1076,8 @@ void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_
   // reads of A, C, G, T only go through the instantiation with 64-triplet tables (three waves per SIMD), the others
   // (flagged by one pass over the bases) through the one with 125; CFR_DUST_SPLIT=0: everything through the latter
   static const bool split = !(dbg_env("CFR_DUST_SPLIT") && atoi(dbg_env("CFR_DUST_SPLIT")) == 0);
-  const unsigned blocks_pure = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 6));
+  static const int pure_per_cu = dbg_env("CFR_DUST_BLOCKS") ? std::max(1, atoi(dbg_env("CFR_DUST_BLOCKS"))) : (CFR_DUST_RINGLESS ? 9 : 6);   // resident blocks of k_dust<true>: 16.6 KB of LDS each without the ring
+  const unsigned blocks_pure = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * pure_per_cu));
   const unsigned blocks_any = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
   uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2,
                                        ((size_t)(blocks_pure + blocks_any) * kDustBlock * 64 + kDustPoolHead) * sizeof(uint32_t));   // one table per stream
