@@ -152,7 +152,7 @@ class BuildInput(C.Structure):
 
 class BuildOptions(C.Structure):
     _fields_ = [("ftab_chars", C.c_int32), ("offrate", C.c_int32), ("device", C.c_int32), ("threads", C.c_int32), ("rbbwt_b", C.c_uint64),
-                ("verbose", C.c_int32), ("reserved", C.c_int32)]
+                ("verbose", C.c_int32), ("protein", C.c_int32)]
 
 
 class BuildReport(C.Structure):
@@ -161,10 +161,11 @@ class BuildReport(C.Structure):
 
 
 def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10, offrate=4, rbbwt_b=0, device=0, threads=0, verbose=False,
-                genome_seq=None, n_extra=0):
+                genome_seq=None, n_extra=0, protein=False):
     """cfr_build_index: the native writer (suffix array on the MI355X).  seqs: list of np.uint8 ASCII arrays, or one
     concatenated array together with the lengths given as (text, lens).  genome_seq: sequence id (index into names) of every
-    genome of the text in text order when that is not 0, 1, 2, ... over all names; the last n_extra names have no tax id."""
+    genome of the text in text order when that is not 0, 1, 2, ... over all names; the last n_extra names have no tax id.
+    protein: seqs are amino-acid strings (letters of ARNDCEQGHILKMFPSTWYV), the index is the one centrifuger-build --protein writes."""
     if isinstance(seqs, tuple):
         text, lens = seqs
         text = np.ascontiguousarray(text, dtype=np.uint8)
@@ -193,6 +194,7 @@ def build_index(names, taxids, seqs, nodes, tax_names, out_prefix, ftab_chars=10
     opt = BuildOptions()
     lib().cfr_build_options_default(C.byref(opt))
     opt.ftab_chars, opt.offrate, opt.device, opt.threads, opt.rbbwt_b, opt.verbose = ftab_chars, offrate, device, threads, rbbwt_b, int(verbose)
+    opt.protein = int(protein)
     rep = BuildReport()
     _check(lib().cfr_build_index(C.byref(inp), C.byref(opt), out_prefix.encode(), C.byref(rep)))
     return {"n": rep.n, "b": rep.block_size, "first_isa": rep.first_isa, "seconds_sa": rep.seconds_sa, "seconds_total": rep.seconds_total,

@@ -127,7 +127,7 @@ uint64_t run_block_len(const uint8_t *S, uint64_t n, uint64_t s, uint64_t e, uin
   }
   return total;
 }
-uint64_t estimate_space(const uint8_t *S, uint64_t n, uint64_t b, uint64_t abits) {           // EstimateSpace (:51-81)
+uint64_t estimate_space(const uint8_t *S, uint64_t n, uint64_t b, uint64_t abits, uint64_t per_symbol_extra = 0) {   // EstimateSpace (:51-81; Sequence_RunBlockOneTree.hpp:52-82 charges one more bit per kept symbol)
   const uint64_t infer_len = 1024, cases = 1024;
   uint64_t rbl = 0, m = 0;
   if (infer_len * cases >= n) { rbl = run_block_len(S, n, 0, n - 1, b); m = n; }
@@ -140,7 +140,7 @@ uint64_t estimate_space(const uint8_t *S, uint64_t n, uint64_t b, uint64_t abits
     }
   }
   const uint64_t rbc = (rbl + b - 1) / b;
-  if (b > 1) return (m + b - 1) / b + abits * (rbc + m - rbl);
+  if (b > 1) return (m + b - 1) / b + (abits + per_symbol_extra) * (rbc + m - rbl);
   return abits * m;
 }
 double avg_run_length(const uint8_t *S, uint64_t n) {                                          // EstimateAverageRunLength (:84-132)
@@ -156,21 +156,20 @@ double avg_run_length(const uint8_t *S, uint64_t n) {                           
   }
   return (double)m / (double)r;
 }
-uint64_t compute_block_size(const uint8_t *S, uint64_t n) {                                   // ComputeBlockSize (:135-177), sigma = 4
-  const uint64_t abits = 2;
+uint64_t compute_block_size(const uint8_t *S, uint64_t n, uint64_t abits = 2, uint64_t extra = 0) {      // ComputeBlockSize (:135-177), sigma = 4; Sequence_RunBlockOneTree.hpp:136-177 with (5, 1)
   uint64_t best_space = 0, best = 0;
   for (uint64_t i = 1; i <= 1024; i *= 2) {
-    const uint64_t sp = estimate_space(S, n, i, abits);
+    const uint64_t sp = estimate_space(S, n, i, abits, extra);
     if (best_space == 0 || sp < best_space) { best_space = sp; best = i; }
   }
   if (best >= 2) {
-    const uint64_t sp = estimate_space(S, n, best / 2 * 3, abits);
+    const uint64_t sp = estimate_space(S, n, best / 2 * 3, abits, extra);
     if (sp < best_space) { best_space = sp; best = best / 2 * 3; }
   }
   const double x = std::sqrt(avg_run_length(S, n));
   const uint64_t test = (double)(uint64_t)x == x ? (uint64_t)x : (uint64_t)x + 1;
   if (test > 2) {
-    const uint64_t sp = estimate_space(S, n, test, abits);
+    const uint64_t sp = estimate_space(S, n, test, abits, extra);
     if (sp < best_space) { best_space = sp; best = test; }
   }
   return best;
@@ -265,7 +264,235 @@ void write_taxonomy(const std::string &path, const BuildInput &in) {
 
 }  // namespace
 
+// ================================================================================================ protein indexes
+// centrifuger-build --protein (CentrifugerBuild.cpp:221-227): FMIndex<Sequence_RunBlockOneTree> over the alphabet
+// "$ARNDCEQGHILKMFPSTWYV" with '$' behind every sequence (SequenceCompactor.hpp:59-87, Builder.hpp:95-101), no fuzzy boundary
+// and no selectedSA (Builder.hpp:224-235), endMarkerSA = the sequence that FOLLOWS each '$' (Builder.hpp:55-67).
+namespace {
+
+const char kProtList[] = "$ARNDCEQGHILKMFPSTWYV";
+constexpr uint32_t kProtSigma = 21, kProtBits = 5;
+
+void write_alphabet_list(Out &o, const char *list, uint32_t sigma, uint32_t bits) {      // Alphabet::InitFromList + Save (Alphabet.hpp:53-69, 194-205)
+  o.u64(sigma); o.i32(1); o.u64(sigma);
+  o.raw(list, sigma);
+  int32_t code[256] = {0};
+  int16_t clen[256] = {0};
+  for (uint32_t i = 0; i < sigma; ++i) { code[(unsigned char)list[i]] = (int32_t)i; clen[(unsigned char)list[i]] = (int16_t)bits; }
+  o.raw(code, sizeof(code));
+  o.raw(clen, sizeof(clen));
+}
+
+// Sequence_WaveletTree::BuildTree (Sequence_WaveletTree.hpp:104-133) for plain codes of `bits` bits: nodes numbered in preorder,
+// a node's bit string holds bit (bits - 1 - depth) of its symbols; a node at the last bit or with no symbols is a leaf
+struct GenNode { uint64_t prefix; int32_t depth, child0, child1; Bits v; };
+int gen_tree(std::vector<GenNode> &nodes, const std::vector<uint8_t> &S, int depth, uint64_t prefix, uint32_t bits) {
+  const int ti = (int)nodes.size();
+  nodes.emplace_back();
+  nodes[(size_t)ti].prefix = prefix; nodes[(size_t)ti].depth = depth; nodes[(size_t)ti].child0 = nodes[(size_t)ti].child1 = -1;
+  {
+    Bits &v = nodes[(size_t)ti].v;
+    v.w.assign((S.size() + 63) / 64, 0);
+    v.n = S.size();
+    const uint32_t sh = bits - 1u - (uint32_t)depth;
+    for (size_t i = 0; i < S.size(); ++i) v.w[i >> 6] |= (uint64_t)((S[i] >> sh) & 1u) << (i & 63);
+  }
+  if ((int)bits - depth == 1 || S.empty()) return ti;
+  std::vector<uint8_t> left, right;
+  {
+    const uint32_t sh = bits - 1u - (uint32_t)depth;
+    size_t ones = 0;
+    for (uint8_t c : S) ones += (c >> sh) & 1u;
+    left.reserve(S.size() - ones); right.reserve(ones);
+    for (uint8_t c : S) ((c >> sh) & 1u ? right : left).push_back(c);
+  }
+  const int c0 = gen_tree(nodes, left, depth + 1, prefix << 1, bits);
+  std::vector<uint8_t>().swap(left);
+  const int c1 = gen_tree(nodes, right, depth + 1, (prefix << 1) | 1ull, bits);
+  nodes[(size_t)ti].child0 = c0; nodes[(size_t)ti].child1 = c1;
+  return ti;
+}
+
+std::vector<uint64_t> pack_fixed64(const std::vector<uint64_t> &vals, int bits) {
+  const uint64_t nw = (vals.size() * (uint64_t)bits + 63) / 64;
+  std::vector<uint64_t> out(nw + 1, 0);
+  for (uint64_t i = 0; i < vals.size(); ++i) {
+    const uint64_t pos = i * (uint64_t)bits, wi = pos >> 6, sh = pos & 63;
+    out[wi] |= vals[i] << sh;
+    if (sh + (uint64_t)bits > 64) out[wi + 1] |= vals[i] >> (64 - sh);
+  }
+  out.resize(nw);
+  return out;
+}
+void write_fixed_array(Out &o, const std::vector<uint64_t> &vals) {       // FixedSizeElemArray::InitFromArray(0, ...) + Save (FixedSizeElemArray.hpp:72-90)
+  uint64_t mx = 0;
+  for (uint64_t v : vals) mx = std::max(mx, v);
+  int bits = 1;
+  while (bits < 64 && (mx >> bits)) ++bits;
+  const std::vector<uint64_t> words = pack_fixed64(vals, bits);
+  o.u64(words.size()); o.i32(bits); o.u64(vals.size()); o.raw(words.data(), words.size() * 8);
+}
+
+void build_protein_index_files(const BuildInput &in, const BuildOptions &opt, const std::string &prefix, BuildReport *rep) {
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto say = [&](const std::string &m) { if (opt.verbose) fprintf(stderr, "[cfr-build] %s\n", m.c_str()); };
+  const uint32_t w = (uint32_t)opt.ftab_chars, rate = 1u << opt.offrate;
+  if (opt.ftab_chars < 1 || opt.ftab_chars > 6) throw std::runtime_error("index build: --ftabchars of a protein index must be in 1..6 (5 bits per character)");
+  if (opt.offrate < 0 || opt.offrate > 16) throw std::runtime_error("index build: --offrate must be in 0..16");
+  const size_t G = in.lens.size();
+  if (G == 0 || in.genome_seq.size() != G) throw std::invalid_argument("index build: the text needs at least one sequence, with one sequence id and one length each");
+  if (in.names.size() != in.taxids.size() + in.n_extra) throw std::invalid_argument("index build: one tax id per conversion-table sequence, none for the extra names");
+  std::vector<uint64_t> psum(G + 1, 0);                 // with the '$' of every sequence
+  {
+    std::vector<uint8_t> seen(in.names.size(), 0);
+    for (size_t g = 0; g < G; ++g) {
+      if (in.genome_seq[g] >= in.names.size()) throw std::invalid_argument("index build: a sequence id is outside the name list");
+      if (seen[in.genome_seq[g]]) throw std::invalid_argument("index build: sequence " + in.names[in.genome_seq[g]] + " appears twice in the text");
+      seen[in.genome_seq[g]] = 1;
+      if (in.lens[g] + 1 < (uint64_t)w + 1) throw std::invalid_argument("index build: sequence " + in.names[in.genome_seq[g]] + " is shorter than --ftabchars");
+      psum[g + 1] = psum[g] + in.lens[g] + 1;
+    }
+  }
+  const uint64_t n = psum[G];
+  if (n >= 0xfffffff0ull) throw std::invalid_argument("index build: a protein text of 2^32 symbols or more is outside this writer");
+  // ---- the text as plain codes
+  std::vector<uint8_t> T(n);
+  {
+    uint8_t code_of[256];
+    memset(code_of, 255, sizeof(code_of));
+    for (uint32_t k = 1; k < kProtSigma; ++k) code_of[(unsigned char)kProtList[k]] = (uint8_t)k;
+    uint64_t src = 0;
+    for (size_t g = 0; g < G; ++g) {
+      uint8_t *dst = T.data() + psum[g];
+      for (uint64_t k = 0; k < in.lens[g]; ++k) {
+        const uint8_t c = code_of[in.text[src + k]];
+        if (c == 255) throw std::runtime_error("index build: the text of a protein index must consist of the letters ARNDCEQGHILKMFPSTWYV only");
+        dst[k] = c;
+      }
+      dst[in.lens[g]] = 0;
+      src += in.lens[g];
+    }
+  }
+  // ---- suffix array (device) and what is read off it
+  std::vector<uint32_t> sa;
+  double sa_seconds = 0;
+  int rounds = 0;
+  build_sa_bytes(T.data(), n, opt.device, sa, &sa_seconds, &rounds);
+  say("suffix array: " + std::to_string(sa_seconds) + " s, " + std::to_string(rounds) + " rounds");
+  auto seq_of = [&](uint64_t pos) -> uint64_t {          // PartialSum::Search: the sequence that holds text position pos
+    size_t k = (size_t)(std::upper_bound(psum.begin(), psum.end(), pos) - psum.begin()) - 1;
+    if (k >= G) k = G - 1;
+    return in.genome_seq[k];
+  };
+  std::vector<uint8_t> B(n);
+  uint64_t first_isa = 0;
+  const uint64_t end_markers = G;                        // one '$' per sequence (the letters themselves never code to 0)
+  const uint64_t nsamp = (n + rate - 1) / rate, nk = 1ull << (kProtBits * w);
+  std::vector<uint64_t> sampled(nsamp), ftab(2 * nk, 0), end_sa(end_markers);
+  for (uint64_t i = 0; i < n; ++i) {
+    const uint64_t p = sa[i];
+    if (p == 0) { first_isa = i; B[i] = T[n - 1]; } else B[i] = T[p - 1];
+    if (i % rate == 0) sampled[i / rate] = seq_of(p);                      // (no fuzzy boundary, Builder.hpp:55-60)
+    if (p + w <= n) {                                                       // FMBuilder.hpp:256-283: T.PackRead(p, w) - the first symbol in the low bits
+      uint64_t key = 0;
+      for (uint32_t k = 0; k < w; ++k) key |= (uint64_t)T[p + k] << (kProtBits * k);
+      if (ftab[2 * key + 1] == 0) ftab[2 * key] = i;
+      ++ftab[2 * key + 1];
+    }
+    if (i < end_markers) end_sa[i] = seq_of(p + 1);                         // rows of the '$' suffixes come first (FMBuilder.hpp:306-311)
+  }
+  std::vector<uint32_t>().swap(sa);
+  std::vector<uint64_t> C(kProtSigma + 1, 0);
+  for (uint64_t i = 0; i < n; ++i) ++C[B[i] + 1u];
+  for (uint32_t k = 1; k <= kProtSigma; ++k) C[k] += C[k - 1];
+  const char last_chr = kProtList[B[first_isa]];
+  std::vector<uint8_t>().swap(T);
+
+  // ---- Sequence_RunBlockOneTree::Init (Sequence_RunBlockOneTree.hpp:227-370)
+  uint64_t b = opt.rbbwt_b ? opt.rbbwt_b : compute_block_size(B.data(), n, kProtBits, 1);
+  if (b == 1) b = n;
+  const uint64_t nblk = (n + b - 1) / b;
+  Bits use;
+  std::vector<Bits> alpha_rb(kProtSigma);
+  std::vector<uint8_t> mixed;
+  mixed.reserve(n);
+  {
+    bool any_run = false;
+    use.w.assign((nblk + 63) / 64, 0);
+    use.n = nblk;
+    for (uint64_t k = 0; k < nblk; ++k) {
+      const uint64_t st = k * b, end = std::min(st + b, n);
+      bool run = true;
+      for (uint64_t q = st + 1; q < end; ++q) if (B[q] != B[st]) { run = false; break; }
+      if (run) { use.w[k >> 6] |= 1ull << (k & 63); any_run = true; }
+    }
+    // b == n without a run: the per-symbol strings stay empty (:276-292, "let rank9 handle the special case")
+    const bool keep_rb = b != n || any_run;
+    for (uint64_t k = 0; k < nblk; ++k) {
+      const uint64_t st = k * b, end = std::min(st + b, n);
+      if ((use.w[k >> 6] >> (k & 63)) & 1ull) { mixed.push_back(B[st]); if (keep_rb) alpha_rb[B[st]].push(1); }
+      else for (uint64_t q = st; q < end; ++q) { mixed.push_back(B[q]); if (keep_rb) alpha_rb[B[q]].push(0); }
+    }
+  }
+  std::vector<uint8_t>().swap(B);
+  std::vector<GenNode> nodes;
+  nodes.reserve(32);
+  gen_tree(nodes, mixed, 0, 0, kProtBits);
+  const uint64_t mixed_n = mixed.size();
+  std::vector<uint8_t>().swap(mixed);
+  say("run-block (one tree): b = " + std::to_string(b) + ", " + std::to_string(nblk) + " blocks, " + std::to_string(mixed_n) + " symbols kept, " +
+      std::to_string(nodes.size()) + " wavelet nodes (" + std::to_string(since()) + " s)");
+
+  // ---- .1.cfr (FMIndex::Save, FMIndex.hpp:571-586; Sequence_RunBlockOneTree::Save :485-497)
+  {
+    Out o(prefix + ".1.cfr");
+    o.u64(n); o.u64(kProtBits); o.u64(first_isa);
+    o.raw(&last_chr, 1);
+    o.u64(0); o.u64(n); write_alphabet_list(o, kProtList, kProtSigma, kProtBits);
+    o.u64(b); o.u64(nblk);
+    write_bitvector(o, use);
+    for (uint32_t k = 0; k < kProtSigma; ++k) write_bitvector(o, alpha_rb[k]);
+    o.u64(0); o.u64(mixed_n); write_alphabet_list(o, kProtList, kProtSigma, kProtBits);
+    o.i32((int32_t)nodes.size()); o.i32(0);
+    for (const GenNode &nd : nodes) { o.u64(nd.prefix); o.i32(nd.depth); o.i32(nd.child0); o.i32(nd.child1); write_bitvector(o, nd.v); }
+    write_alphabet_list(o, kProtList, kProtSigma, kProtBits); write_alphabet_list(o, kProtList, kProtSigma, kProtBits);
+    o.raw(C.data(), C.size() * 8);
+    o.u64(n); o.i32(0); o.i32((int32_t)rate); o.u64(nsamp); o.u64(w); o.u64(nk); o.u64(0);       // adjustedSA0 stays 0 with end markers (FMBuilder.hpp:68)
+    write_fixed_array(o, sampled);
+    o.raw(ftab.data(), ftab.size() * 8);
+    o.u64(0);                                                    // maxLcp
+    o.u64(0); o.i32(1024);                                       // no selectedSA
+    const char one = 1;
+    o.raw(&one, 1);                                              // hasEndMarker
+    write_fixed_array(o, end_sa);
+    o.close();
+  }
+  write_taxonomy(prefix + ".2.cfr", in);
+  {
+    Out o(prefix + ".3.cfr");
+    std::map<uint64_t, uint64_t> by_id;                        // lengths count the '$' (Builder.hpp:143-156: what Compact returned)
+    for (size_t g = 0; g < G; ++g) by_id[in.genome_seq[g]] = in.lens[g] + 1;
+    for (const auto &kv : by_id) { o.u64(kv.first); o.u64(kv.second); }
+    o.close();
+  }
+  {
+    Out o(prefix + ".4.cfr");
+    char stime[128];
+    const time_t now = time(nullptr);
+    strftime(stime, sizeof(stime), "%c", localtime(&now));
+    const std::string txt = "version\t1.1.3-r347\nSA_sample_rate\t" + std::to_string(rate) + "\nsequence_type\tamino_acid\nbuild_date\t" + stime;
+    o.raw(txt.data(), txt.size());
+    o.close();
+  }
+  say("protein index written to " + prefix + ".*.cfr in " + std::to_string(since()) + " s");
+  if (rep) { rep->n = n; rep->block_size = b; rep->first_isa = first_isa; rep->seconds_sa = sa_seconds; rep->seconds_total = since(); rep->rounds = rounds; }
+}
+
+}  // namespace
+
 void build_index_files(const BuildInput &in, const BuildOptions &opt, const std::string &prefix, BuildReport *rep) {
+  if (opt.protein) { build_protein_index_files(in, opt, prefix, rep); return; }
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   auto say = [&](const std::string &m) { if (opt.verbose) fprintf(stderr, "[cfr-build] %s\n", m.c_str()); };

@@ -31,6 +31,10 @@ void build_sa_products(const uint8_t *text, uint64_t n, int device, uint32_t sam
                        const std::vector<uint64_t> &psum, const std::vector<uint64_t> &want_pos, SaProducts &out,
                        const std::function<void(const std::string &)> &log);
 
+// Suffix array of a text of byte codes (protein indexes: 21 codes, '$' = 0 closes every sequence), n < 2^32: prefix doubling with
+// hipCUB radix sorts in HBM (cfr_build_sa.hip).  Same order as above: plain lexicographic, a proper prefix first.
+void build_sa_bytes(const uint8_t *codes, uint64_t n, int device, std::vector<uint32_t> &sa, double *seconds, int *rounds);
+
 struct TaxNode { uint64_t taxid, parent; std::string rank; };
 struct BuildInput {
   std::vector<std::string> names;          // sequence names, conversion-table order = sequence ids; the last n_extra are extra names (no tax id)
@@ -38,11 +42,12 @@ struct BuildInput {
   std::vector<uint64_t> present_taxids;    // further ids the conversion table mentions (their lineages stay in the tree)
   uint64_t n_extra = 0;
   std::vector<uint64_t> genome_seq, lens;  // the genomes of the text, text order: sequence id and length (ACGT only)
-  const uint8_t *text = nullptr;           // the genomes back to back, upper-case ACGT
+  const uint8_t *text = nullptr;           // the genomes back to back, upper-case ACGT (BuildOptions::protein: the proteins back to back, letters of
+                                           // "ARNDCEQGHILKMFPSTWYV" only; lens are residue counts, the writer puts '$' behind every protein)
   std::vector<TaxNode> nodes;              // nodes.dmp
   std::vector<std::pair<uint64_t, std::string>> tax_names;   // names.dmp, scientific names
 };
-struct BuildOptions { int ftab_chars = 10, offrate = 4, device = 0, threads = 0; uint64_t rbbwt_b = 0; bool verbose = false; };
+struct BuildOptions { int ftab_chars = 10, offrate = 4, device = 0, threads = 0; uint64_t rbbwt_b = 0; bool verbose = false, protein = false; };
 struct BuildReport { uint64_t n = 0, block_size = 0, first_isa = 0; double seconds_sa = 0, seconds_total = 0; int rounds = 0; };
 
 // Writes <prefix>.{1,2,3,4}.cfr.  Throws HipError / IoError / std::runtime_error.

@@ -3,8 +3,8 @@
 // Same option names as the reference's builder (CentrifugerBuild.cpp:34-52) for what the MI355X writer covers:
 // nucleotide references, one sequence per conversion-table line, default layout or --rbbwt-b / --offrate / --ftabchars.
 // --bmax / --dcv / --build-mem steer the reference's blockwise sorter (FMBuilder.hpp:444-811) and have no meaning here
-// (the suffix array is built in HBM): accepted and ignored.  Options of other parts of the builder (--protein,
-// --subset-tax, --concat-tax-genome, --checkpoint, file-level conversion tables) are rejected with a message.
+// (the suffix array is built in HBM): accepted and ignored.  --protein writes the amino-acid index (FMIndex<Sequence_RunBlockOneTree>,
+// '$' behind every sequence).  Options of other parts of the builder (--subset-tax, --concat-tax-genome, --checkpoint, file-level conversion tables) are rejected with a message.
 // Input handling follows Builder::Build (Builder.hpp:108-165) and Taxonomy::ReadSeqNameFile (Taxonomy.hpp:303-368): the text is
 // formed in FASTA order; a conversion table may name sequences the FASTA does not hold (they keep their ids and tax ids in
 // .2.cfr, have no length in .3.cfr); a FASTA sequence the table does not name is added as an extra name with a warning (or
@@ -42,12 +42,13 @@ const char *kUsage =
     "\t--offrate INT: SA/offset is sampled every (2^<int>) BWT chars [4]\n"
     "\t--ftabchars INT: # of chars consumed in initial lookup [10]\n"
     "\t--rbbwt-b INT: block size for run-block compressed BWT. 0 for auto. 1 for no compression [0]\n"
+    "\t--protein: the input is protein sequences [off]\n"
     "\t--ignore-uncategorized-genome: do not index a sequence that is missing from the conversion table\n"
     "\t--gpu INT: MI355X ordinal that builds the suffix array [0]\n"
     "\t--bmax / --dcv / --build-mem: accepted and ignored (they steer the reference's blockwise sorter)\n"
     "\t-h: print this usage message\n";
 
-enum { O_BMAX = 1000, O_DCV, O_MEM, O_OFFRATE, O_FTAB, O_RBB, O_TREE, O_CONV, O_NAMES, O_GPU, O_IGNORE_UNCAT, O_UNSUPPORTED };
+enum { O_BMAX = 1000, O_DCV, O_MEM, O_OFFRATE, O_FTAB, O_RBB, O_TREE, O_CONV, O_NAMES, O_GPU, O_IGNORE_UNCAT, O_PROTEIN, O_UNSUPPORTED };
 
 void print_log(const char *fmt, ...) {
   char buffer[1024];
@@ -102,11 +103,11 @@ int main(int argc, char *argv[]) {
       {"offrate", required_argument, 0, O_OFFRATE}, {"ftabchars", required_argument, 0, O_FTAB}, {"rbbwt-b", required_argument, 0, O_RBB},
       {"taxonomy-tree", required_argument, 0, O_TREE}, {"conversion-table", required_argument, 0, O_CONV}, {"name-table", required_argument, 0, O_NAMES},
       {"gpu", required_argument, 0, O_GPU}, {"subset-tax", required_argument, 0, O_UNSUPPORTED}, {"concat-tax-genome", no_argument, 0, O_UNSUPPORTED},
-      {"checkpoint", no_argument, 0, O_UNSUPPORTED}, {"protein", no_argument, 0, O_UNSUPPORTED},
+      {"checkpoint", no_argument, 0, O_UNSUPPORTED}, {"protein", no_argument, 0, O_PROTEIN},
       {"ignore-uncategorized-genome", no_argument, 0, O_IGNORE_UNCAT}, {0, 0, 0, 0}};
   std::vector<std::string> fasta;
   std::string out_prefix = "centrifuger", tree, names_dmp, conv;
-  bool ignore_uncategorized = false;
+  bool ignore_uncategorized = false, ftab_given = false;
   cfr_build_options opt;
   cfr_build_options_default(&opt);
   opt.verbose = 1;
@@ -133,13 +134,14 @@ int main(int argc, char *argv[]) {
       case 'h': fprintf(stderr, "%s", kUsage); return 0;
       case O_BMAX: case O_DCV: case O_MEM: break;
       case O_OFFRATE: opt.offrate = atoi(optarg); break;
-      case O_FTAB: opt.ftab_chars = atoi(optarg); break;
+      case O_FTAB: opt.ftab_chars = atoi(optarg); ftab_given = true; break;
       case O_RBB: opt.rbbwt_b = strtoull(optarg, nullptr, 10); break;
       case O_TREE: tree = optarg; break;
       case O_CONV: conv = optarg; break;
       case O_NAMES: names_dmp = optarg; break;
       case O_GPU: opt.device = atoi(optarg); break;
       case O_IGNORE_UNCAT: ignore_uncategorized = true; break;
+      case O_PROTEIN: opt.protein = 1; break;
       case O_UNSUPPORTED:
         print_log("ERROR: option --%s belongs to a part of centrifuger-build outside the MI355X writer and is not available in this build.",
                   long_options[option_index].name);
@@ -147,6 +149,9 @@ int main(int argc, char *argv[]) {
       default: fprintf(stderr, "%s", kUsage); return EXIT_FAILURE;
     }
   }
+  // --protein: alphabet "$ARNDCEQGHILKMFPSTWYV", 4 characters in the initial lookup unless --ftabchars says otherwise (CentrifugerBuild.cpp:221-227:
+  // the reference tests "width == 10", so an explicit --ftabchars 10 becomes 4 there too)
+  if (opt.protein && (!ftab_given || opt.ftab_chars == 10)) opt.ftab_chars = 4;
   if (fasta.empty()) { print_log("Need to use -r/-l to specify the reference sequences."); return EXIT_FAILURE; }
   if (tree.empty() || names_dmp.empty() || conv.empty()) { print_log("Need to use --taxonomy-tree, --name-table and --conversion-table."); return EXIT_FAILURE; }
 
@@ -236,7 +241,7 @@ int main(int argc, char *argv[]) {
     auto close_record = [&]() {
       if (!keep) return;
       const size_t len = text.size() - cur_start;
-      if (len < (size_t)opt.ftab_chars + 1) {   // a genome too short (Builder.hpp:143-150): filtered, and its id is not taken
+      if (len + (opt.protein ? 1 : 0) < (size_t)opt.ftab_chars + 1) {   // a genome too short (Builder.hpp:143-150; a protein's '$' counts): filtered, and its id is not taken
         fprintf(stderr, "WARNING: %s is filtered due to its short length (could be from masker)!\n", cur_name.c_str());
         text.resize(cur_start);
       } else {
@@ -282,7 +287,10 @@ int main(int argc, char *argv[]) {
           }
           if (at_line_start && ch == '>') { in_header = true; header.clear(); continue; }
           at_line_start = ch == '\n';
-          if (keep && (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T')) text.push_back((uint8_t)ch);
+          if (keep && (opt.protein ? (ch > 0 && strchr("ARNDCEQGHILKMFPSTWYV$", ch) != nullptr) : (ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T'))) {
+            if (ch == '$') { print_log("ERROR: a '$' inside a protein sequence is outside this writer."); return EXIT_FAILURE; }
+            text.push_back((uint8_t)ch);
+          }
         }
       }
       if (in_header) open_record(header.substr(0, header.find_first_of(" \t\r")));      // (a file that ends inside a header line)

@@ -233,7 +233,7 @@ cfr_status cfr_build_index(const cfr_build_input *in, const cfr_build_options *o
     for (uint64_t i = 0; i < in->n_nodes; ++i) bi.nodes.push_back(cfr::TaxNode{in->node_taxid[i], in->node_parent[i], in->node_rank[i] ? in->node_rank[i] : ""});
     for (uint64_t i = 0; i < in->n_names; ++i) bi.tax_names.emplace_back(in->name_taxid[i], in->name_text[i] ? in->name_text[i] : "");
     cfr::BuildOptions bo;
-    if (opt) { bo.ftab_chars = opt->ftab_chars; bo.offrate = opt->offrate; bo.device = opt->device; bo.threads = opt->threads; bo.rbbwt_b = opt->rbbwt_b; bo.verbose = opt->verbose != 0; }
+    if (opt) { bo.ftab_chars = opt->ftab_chars; bo.offrate = opt->offrate; bo.device = opt->device; bo.threads = opt->threads; bo.rbbwt_b = opt->rbbwt_b; bo.verbose = opt->verbose != 0; bo.protein = opt->protein != 0; }
     cfr::BuildReport rep;
     cfr::build_index_files(bi, bo, out_prefix, &rep);
     if (report) {

@@ -317,7 +317,10 @@ typedef struct {
   int32_t device;       /* HIP device ordinal */
   int32_t threads;      /* host threads of the compression / writing half, 0 = automatic */
   uint64_t rbbwt_b;     /* --rbbwt-b, 0 = automatic block size */
-  int32_t verbose, reserved;
+  int32_t verbose;
+  int32_t protein;      /* --protein (CentrifugerBuild.cpp:221-227, Builder.hpp:95-101): `text` holds the proteins back to back, letters of
+                         * "ARNDCEQGHILKMFPSTWYV" only, lengths in residues; the writer closes every protein with '$' and writes an
+                         * FMIndex<Sequence_RunBlockOneTree> with endMarkerSA.  ftab_chars <= 6 (the reference's default is 4), n < 2^32 */
 } cfr_build_options;
 typedef struct {
   uint64_t n, block_size, first_isa;

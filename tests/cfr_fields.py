@@ -3,7 +3,8 @@ fields are reported as 'SPACE' so that two writers can be compared on everything
 import struct
 
 
-def parse_1cfr(path):
+def parse_1cfr(path, protein=False):
+    """protein: FMIndex<Sequence_RunBlockOneTree> with end markers (centrifuger-build --protein)."""
     d = open(path, "rb").read()
     pos = [0]
     out = []
@@ -44,11 +45,20 @@ def parse_1cfr(path):
                 bitvec(f"{tag}.node{k}.v")
 
     u64("n"); u64("abits"); u64("firstISA"); raw("lastChr", 1)
-    u64("rb.space", True); u64("rb.n"); alpha("rb.alpha"); u64("b"); u64("blockCnt")
-    bitvec("useRunBlock"); wavelet("wave"); wavelet("runs")
-    alpha("alphabets"); alpha("plain"); raw("C", 40)
+    u64("rb.space", True); u64("rb.n"); sigma = alpha("rb.alpha"); u64("b"); u64("blockCnt")
+    if protein:
+        bitvec("useRunBlock")
+        for k in range(sigma):
+            bitvec(f"alphabetRB{k}")
+        wavelet("compressed")
+        alpha("alphabets"); alpha("plain"); raw("C", 8 * (sigma + 1))
+    else:
+        bitvec("useRunBlock"); wavelet("wave"); wavelet("runs")
+        alpha("alphabets"); alpha("plain"); raw("C", 40)
     u64("aux.n"); i32("strategy"); i32("rate"); u64("sampleSize"); u64("width"); ps = u64("psize"); u64("adjSA0")
     u64("fsea.size"); l = i32("fsea.l"); fn = u64("fsea.n"); raw("fsea.W", (fn * l + 63) // 64 * 8)
     raw("ftab", ps * 16); u64("maxLcp"); sc = u64("selCnt"); i32("filterRate"); raw("sel", sc * 16); raw("hasEnd", 1)
+    if protein:
+        u64("end.size"); l = i32("end.l"); fn = u64("end.n"); raw("end.W", (fn * l + 63) // 64 * 8)
     assert pos[0] == len(d), (pos[0], len(d))
     return out

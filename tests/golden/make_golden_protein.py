@@ -84,6 +84,13 @@ def main():
     with open(os.path.join(tmp, "names.dmp"), "w") as f:
         for t, nm in names:
             f.write(f"{t}\t|\t{nm}\t|\t\t|\tscientific name\t|\n")
+    # the builder's inputs are fixtures too: the native protein writer (cfr_build_index, protein = 1) is checked against the
+    # .cfr files below on exactly these files (tests/test_gpu_build_protein.py)
+    os.makedirs(os.path.join(OUT, "input"), exist_ok=True)
+    for fn in ("prot.fa", "seqid.map", "nodes.dmp", "names.dmp"):
+        shutil.copy(os.path.join(tmp, fn), os.path.join(OUT, "input", fn))
+    if "--inputs-only" in sys.argv:
+        return
     build = [os.path.join(REF, "centrifuger-build"), "--protein", "-t", "4", "-r", os.path.join(tmp, "prot.fa"), "--taxonomy-tree", os.path.join(tmp, "nodes.dmp"),
              "--name-table", os.path.join(tmp, "names.dmp"), "--conversion-table", os.path.join(tmp, "seqid.map")]
     variants = {"p2": ["--ftabchars", "2"], "p3_b4": ["--ftabchars", "3", "--rbbwt-b", "4"], "p2_b1_off2": ["--ftabchars", "2", "--rbbwt-b", "1", "--offrate", "2"],
