@@ -616,11 +616,29 @@ def protein_mode(torch, capi, args, device):
             for t, nm in names:
                 f.write(f"{t}\t|\t{nm}\t|\t\t|\tscientific name\t|\n")
         log(f"proteome: {total/1e6:.1f} M amino acids in {len(starts)} proteins, {time.time()-t0:.1f}s")
+        # the index is written by the native writer (cfr_build_index, protein = 1: suffix array of the byte text on this GPU);
+        # --prot-ref-build also runs the reference's centrifuger-build --protein on the same files and compares what the two wrote
         t0 = time.time()
-        subprocess.run([os.path.join(ref_dir, "centrifuger-build"), "--protein", "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "prot.fa"),
-                        "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
-                        "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        log(f"protein index built by the reference's centrifuger-build --protein in {time.time()-t0:.1f}s")
+        seq_names = [f"P{sp}_{k}_{pi}" for sp in range(n_sp) for k in range(n_st) for pi in range(n_pr)]
+        seq_tids = [1000 + sp * 10 + 1 + k for sp in range(n_sp) for k in range(n_st) for pi in range(n_pr)]
+        rep = capi.build_index(seq_names, seq_tids, (np.concatenate(flat), np.array([len(q) for q in flat], dtype=np.uint64)), nodes, names, prefix,
+                               ftab_chars=4, protein=True, device=device.index or 0)
+        build_info = {"builder": "cfr_build_index (protein)", "n": int(rep["n"]), "seconds_total": time.time() - t0, "seconds_sa": rep["seconds_sa"],
+                      "rounds": rep["rounds"], "block_size": int(rep["b"])}
+        log(f"protein index ({rep['n']/1e6:.1f} M symbols) written by the native writer in {build_info['seconds_total']:.1f}s (suffix array {rep['seconds_sa']:.2f}s, {rep['rounds']} rounds)")
+        if args.prot_ref_build and os.path.exists(os.path.join(ref_dir, "centrifuger-build")):
+            t0 = time.time()
+            subprocess.run([os.path.join(ref_dir, "centrifuger-build"), "--protein", "-t", str(min(os.cpu_count() or 1, args.build_threads)), "-r", os.path.join(cache, "prot.fa"),
+                            "--taxonomy-tree", os.path.join(cache, "nodes.dmp"), "--name-table", os.path.join(cache, "names.dmp"),
+                            "--conversion-table", os.path.join(cache, "seqid.map"), "-o", prefix + "_ref"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            build_info["reference_builder_seconds"] = time.time() - t0
+            a, b = capi.Index(prefix), capi.Index(prefix + "_ref")
+            build_info["digest_equals_reference_built_index"] = a.digest() == b.digest()
+            build_info["taxonomy_file_identical"] = open(prefix + ".2.cfr", "rb").read() == open(prefix + "_ref.2.cfr", "rb").read()
+            a.close(); b.close()
+            log(f"reference's centrifuger-build --protein: {build_info['reference_builder_seconds']:.1f}s; parsed indexes equal: {build_info['digest_equals_reference_built_index']}")
+        with open(prefix + ".build.json", "w") as f:
+            json.dump(build_info, f)
         open(prefix + ".done", "w").close()
     cat = np.load(os.path.join(cache, "prot_cat.npy"))
     starts = np.load(os.path.join(cache, "prot_starts.npy"))
@@ -666,10 +684,12 @@ def protein_mode(torch, capi, args, device):
     out = {"metric": "classified reads/sec (150 bp, translated search against a protein index)", "value": n * args.steps / el, "unit": "reads/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u64", "data": "synthetic",
-           "config": {"workload": f"{info.n/1e6:.0f} M-symbol protein index ({n_sp} species x {n_st} strains x {n_pr} proteins, written by the reference's "
-                                  f"centrifuger-build --protein), {n} x 150 bp DNA reads per step, -k {k}, inputs resident in HBM", "index_symbols": int(info.n)},
+           "config": {"workload": f"{info.n/1e6:.0f} M-symbol protein index ({n_sp} species x {n_st} strains x {n_pr} proteins, written by cfr_build_index, "
+                                  f"protein = 1), {n} x 150 bp DNA reads per step, -k {k}, inputs resident in HBM", "index_symbols": int(info.n)},
            "classified_fraction": float((results["n_match"] > 0).mean()),
            "stage_ms": {kk: float(np.mean([getattr(s_, kk) for s_ in kst])) for kk in ("search_ms", "adjust_ms", "rows_ms", "locate_ms", "tail_ms", "total_ms")}}
+    if os.path.exists(prefix + ".build.json"):
+        out["index"] = json.load(open(prefix + ".build.json"))
     if getattr(args, "inner", False):
         print(json.dumps(out), flush=True)
         dev.close()
@@ -819,6 +839,7 @@ def main():
                                                                   "0 = BASELINE configs[1] (1 Gbp, the metric's config)")
     ap.add_argument("--cache", default=os.environ.get("CFR_BENCH_CACHE", "/tmp/cfr_bench"))
     ap.add_argument("--prot-species", type=int, default=200, help="--mode protein: species of the synthetic proteome (x 5 strains x 400 proteins x ~300 aa)")
+    ap.add_argument("--prot-ref-build", action="store_true", help="--mode protein: also build the index with oracle/_ref/centrifuger-build --protein and compare")
     ap.add_argument("--mode", choices=["se", "pe", "long", "protein"], default="se",
                     help="se = BASELINE configs[1] (default, the metric's config); pe = configs[2]: 2x150 bp pairs, -k 5; "
                          "long = configs[4]-style reads (5-20 kbp, 3%% del / 3%% ins / 4%% sub) on the 1 Gbp index")

@@ -390,17 +390,40 @@ void build_protein_index_files(const BuildInput &in, const BuildOptions &opt, co
   const uint64_t end_markers = G;                        // one '$' per sequence (the letters themselves never code to 0)
   const uint64_t nsamp = (n + rate - 1) / rate, nk = 1ull << (kProtBits * w);
   std::vector<uint64_t> sampled(nsamp), ftab(2 * nk, 0), end_sa(end_markers);
-  for (uint64_t i = 0; i < n; ++i) {
-    const uint64_t p = sa[i];
-    if (p == 0) { first_isa = i; B[i] = T[n - 1]; } else B[i] = T[p - 1];
-    if (i % rate == 0) sampled[i / rate] = seq_of(p);                      // (no fuzzy boundary, Builder.hpp:55-60)
-    if (p + w <= n) {                                                       // FMBuilder.hpp:256-283: T.PackRead(p, w) - the first symbol in the low bits
-      uint64_t key = 0;
-      for (uint32_t k = 0; k < w; ++k) key |= (uint64_t)T[p + k] << (kProtBits * k);
-      if (ftab[2 * key + 1] == 0) ftab[2 * key] = i;
-      ++ftab[2 * key + 1];
+  {
+    // row ranges in parallel; a range keeps its own (first row, count) table for the keys it meets and the tables are merged in
+    // range order, so "first" is the smallest row of a key exactly as in the reference's single pass
+    int threads = opt.threads > 0 ? (int)std::min<uint64_t>((uint64_t)opt.threads, n)
+                                  : (int)std::min<uint64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, n >> 20));
+    std::vector<std::vector<uint64_t>> part((size_t)threads);
+    std::vector<uint64_t> fi((size_t)threads, ~0ull);
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t) th.emplace_back([&, t]() {
+      std::vector<uint64_t> &ft = part[(size_t)t];
+      ft.assign(2 * nk, 0);
+      const uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+      for (uint64_t i = lo; i < hi; ++i) {
+        const uint64_t p = sa[i];
+        if (p == 0) { fi[(size_t)t] = i; B[i] = T[n - 1]; } else B[i] = T[p - 1];
+        if (i % rate == 0) sampled[i / rate] = seq_of(p);                      // (no fuzzy boundary, Builder.hpp:55-60)
+        if (p + w <= n) {                                                       // FMBuilder.hpp:256-283: T.PackRead(p, w) - the first symbol in the low bits
+          uint64_t key = 0;
+          for (uint32_t k = 0; k < w; ++k) key |= (uint64_t)T[p + k] << (kProtBits * k);
+          if (ft[2 * key + 1] == 0) ft[2 * key] = i;
+          ++ft[2 * key + 1];
+        }
+        if (i < end_markers) end_sa[i] = seq_of(p + 1);                         // rows of the '$' suffixes come first (FMBuilder.hpp:306-311)
+      }
+    });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < threads; ++t) {
+      if (fi[(size_t)t] != ~0ull) first_isa = fi[(size_t)t];
+      const std::vector<uint64_t> &ft = part[(size_t)t];
+      for (uint64_t k = 0; k < nk; ++k) if (ft[2 * k + 1]) {
+        if (ftab[2 * k + 1] == 0) ftab[2 * k] = ft[2 * k];
+        ftab[2 * k + 1] += ft[2 * k + 1];
+      }
     }
-    if (i < end_markers) end_sa[i] = seq_of(p + 1);                         // rows of the '$' suffixes come first (FMBuilder.hpp:306-311)
   }
   std::vector<uint32_t>().swap(sa);
   std::vector<uint64_t> C(kProtSigma + 1, 0);

@@ -72,6 +72,7 @@ int main(int argc, char **argv) {
   opt.ftab_chars = atoi(argv[6]);
   if (argc > 7) opt.offrate = atoi(argv[7]);
   if (argc > 8) opt.rbbwt_b = strtoull(argv[8], nullptr, 10);
+  if (argc > 9) opt.threads = atoi(argv[9]);
   cfr::BuildReport rep;
   cfr::build_index_files(in, opt, argv[5], &rep);
   return 0;
