@@ -658,6 +658,9 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   }
   view_.max_entries = (uint64_t)(int64_t)(h.params.max_result * h.params.max_result_per_hit_factor);   // int*int -> size_t (Classifier.hpp:620)
   view_.locate_all = (h.params.max_result_per_hit_factor <= 0 || h.params.max_result <= 0) ? 1 : 0;
+  // the finished description once more in device memory, for the kernels that take it by pointer (k_adjust_tail_p)
+  d_view_ = dev_alloc<DevView>(1);
+  HIP_CHECK(hipMemcpy(d_view_, &view_, sizeof(DevView), hipMemcpyHostToDevice));
 }
 
 DeviceIndex::~DeviceIndex() { release(); }
@@ -1497,7 +1500,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         uint64_t *heavy2 = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVYB1 : S_HEAVYB, std::max(sb, cnt) * 32) : nullptr;
         // beside a search the post stage gets a few blocks per CU (grid-stride inside), alone the whole sub-batch at once
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
-        if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+        // pairs: the image description behind a pointer (k_adjust_tail_p: no 1 KB copy into every lane's scratch); CFR_TAIL_VIEW_PTR=0: by value
+        static const bool view_ptr = !(dbg_env("CFR_TAIL_VIEW_PTR") && atoi(dbg_env("CFR_TAIL_VIEW_PTR")) == 0);
+        if (paired && view_ptr && d_view_) k_adjust_tail_p<4><<<tail_grid, kBlock, 0, ts>>>(d_view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
+        else if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                       pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
         else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
                                                                pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);

@@ -224,6 +224,7 @@ class DeviceIndex {
   int device_;
   hipStream_t stream_ = nullptr;
   DevView view_{};
+  DevView *d_view_ = nullptr;            // view_ in device memory (owned_): kernels that index its arrays take it by pointer
   std::vector<void *> owned_, temps_;     // device allocations of the image / load-time temporaries still alive
   uint64_t device_bytes_ = 0;
   struct Slot { void *p = nullptr; size_t cap = 0; };
