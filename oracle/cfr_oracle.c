@@ -548,9 +548,11 @@ static int set_has(const u64vec *v, uint64_t x) {
   return lo < v->n && v->a[lo] == x;
 }
 
-/* Taxonomy::LCA (Taxonomy.hpp:733-836), lcaChildTaxIds == NULL form */
-uint64_t ora_tax_lca(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt) {
+/* Taxonomy::LCA (Taxonomy.hpp:733-836).  children != NULL: the lcaChildTaxIds bookkeeping (:771-777, :806-813, :822-830) -
+ * one ordered set per backbone node, the LCA's set handed back (compact ids, ascending = std::map order) */
+static uint64_t tax_lca(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt, u64vec *children) {
   int i, j, k;
+  if (children) children->n = 0;
   for (i = 0; i < taxCnt; ++i) if (taxIds[i] != t->rootCTaxId) break;
   if (i < taxCnt) k = i; else return t->rootCTaxId;
   u64vec path = {0}, cnt = {0}, tmp = {0};
@@ -558,6 +560,11 @@ uint64_t ora_tax_lca(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt) 
   do { u64_push(&path, x); u64_push(&cnt, 1); x = t->parent[x]; } while (x != t->parent[x]);
   u64_push(&path, t->rootCTaxId); u64_push(&cnt, 1);
   int backboneLen = (int)path.n;
+  u64vec *bbChild = NULL;                                   /* backboneChildTaxIds (:771-777) */
+  if (children) {
+    bbChild = xcalloc((size_t)backboneLen, sizeof(u64vec));
+    for (j = 1; j < backboneLen; ++j) set_insert(&bbChild[j], path.a[j - 1]);
+  }
   int rootCount = 0;
   for (i = 0; i < taxCnt; ++i) {
     if (i == k) continue;
@@ -571,24 +578,46 @@ uint64_t ora_tax_lca(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt) 
       if (tmp.a[it] != path.a[ib]) break;
       cnt.a[ib] += 1;
     }
+    if (children && it >= 0 && ib + 1 < backboneLen) set_insert(&bbChild[ib + 1], tmp.a[it]);   /* :812-813: where the two paths part */
   }
   for (j = 0; j < backboneLen; ++j) if ((int)cnt.a[j] == taxCnt - rootCount) break;
   uint64_t ret = j >= backboneLen ? t->rootCTaxId : path.a[j];
+  if (children) {
+    if (j < backboneLen) for (size_t q = 0; q < bbChild[j].n; ++q) u64_push(children, bbChild[j].a[q]);
+    for (j = 0; j < backboneLen; ++j) free(bbChild[j].a);
+    free(bbChild);
+  }
   free(path.a); free(cnt.a); free(tmp.a);
   return ret;
 }
+uint64_t ora_tax_lca(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt) { return tax_lca(t, taxIds, taxCnt, NULL); }
 
-/* Taxonomy::ReduceTaxIds (Taxonomy.hpp:839-973), promotedChildTaxIds == NULL form.
- * returns number of promoted ids written to out */
-int ora_tax_reduce(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt, int k, uint64_t *out, int outCap) {
+/* Taxonomy::ReduceTaxIds (Taxonomy.hpp:839-973).  returns number of promoted ids written to out.
+ * child != NULL (promotedChildTaxIds): child[0..*nchild) receives one list per pushed vector - the caller compares *nchild with
+ * the return value exactly as Classifier.hpp:823 does; the lists hold COMPACT ids in the order the reference pushes them. */
+static int tax_reduce(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt, int k, uint64_t *out, int outCap,
+                      u64vec *child, int *nchild) {
   int i, n = 0;
+  if (nchild) *nchild = 0;
   if (taxCnt <= k) {
     for (i = 0; i < taxCnt && i < outCap; ++i) out[i] = taxIds[i];
     return taxCnt;
   }
   for (i = 0; i < taxCnt; ++i)
-    if (taxIds[i] >= t->nodeCnt) { out[0] = t->nodeCnt; return 1; }
-  if (k == 1) { out[0] = ora_tax_lca(t, taxIds, taxCnt); return 1; }
+    if (taxIds[i] >= t->nodeCnt) {
+      out[0] = t->nodeCnt;
+      if (child) {                                         /* :866-872: every input id, in input order */
+        child[0].n = 0;
+        for (int j = 0; j < taxCnt; ++j) u64_push(&child[0], taxIds[j]);
+        *nchild = 1;
+      }
+      return 1;
+    }
+  if (k == 1) {
+    if (child) { out[0] = tax_lca(t, taxIds, taxCnt, &child[0]); *nchild = 1; }
+    else out[0] = tax_lca(t, taxIds, taxCnt, NULL);
+    return 1;
+  }
 
   u64vec inRank[RANK_MAX];
   memset(inRank, 0, sizeof(inRank));
@@ -610,13 +639,32 @@ int ora_tax_reduce(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt, in
   for (ri = 0; ri < t->taxRankNum[RANK_UNKNOWN]; ++ri) if ((int)inRank[ri].n <= k) break;
   for (size_t q = 0; q < inRank[ri].n && n < outCap; ++q) out[n++] = inRank[ri].a[q];
   if (n == 0) out[n++] = t->rootCTaxId;
+  else if (child && ri > 0) {                              /* :939-971 */
+    for (i = 0; i < n; ++i) child[i].n = 0;
+    *nchild = n;
+    for (size_t q = 0; q < inRank[ri - 1].n; ++q) {
+      uint64_t x = inRank[ri - 1].a[q];
+      while (x != t->parent[x]) {
+        x = t->parent[x];
+        if (t->taxRankNum[t->rank[x]] > ri) break;
+        else if (t->taxRankNum[t->rank[x]] == ri) {
+          for (i = 0; i < n; ++i) if (out[i] == x) { u64_push(&child[i], inRank[ri - 1].a[q]); break; }   /* promotedTaxIdIdx */
+          break;
+        }
+      }
+    }
+  }
   for (i = 0; i < RANK_MAX; ++i) free(inRank[i].a);
   return n;
+}
+int ora_tax_reduce(const ora_taxonomy *t, const uint64_t *taxIds, int taxCnt, int k, uint64_t *out, int outCap) {
+  return tax_reduce(t, taxIds, taxCnt, k, out, outCap, NULL, NULL);
 }
 
 /* ======================================================================== L3 classifier */
 
 void ora_param_default(ora_param *p) {   /* Classifier.hpp:28-37 */
+  p->outputExpandedResult = 0;
   p->maxResult = 1; p->minHitLen = 0; p->maxResultPerHitFactor = 40;
   p->considerSecondaryHitLen = 2000; p->considerSecondaryScoreFactor = 0.995;
 }
@@ -993,22 +1041,39 @@ size_t ora_get_classification_from_hits(const ora_index *idx, const ora_hitvec *
   }
 
   result->nmatch = 0;
+  free(result->expanded); result->expanded = NULL;
+  memset(result->expOff, 0, sizeof(result->expOff));
   if ((int)best.n <= P->maxResult || P->maxResult <= 0) {
     if (best.n > ORA_MAX_MATCH) { fprintf(stderr, "oracle: more than %d matches for a read\n", ORA_MAX_MATCH); abort(); }
     for (size_t q = 0; q < best.n; ++q) {
       result->kind[q] = 0; result->id[q] = best.a[q];
       result->taxid[q] = tax_orig(&idx->tax, tax_seq_to_tax(&idx->tax, best.a[q]));
-    }
+    }                                                      /* (:792-795: an empty expanded string per sequence-level match) */
     result->nmatch = (int32_t)best.n;
   } else {
     uint64_t *tids = xmalloc(best.n * 8);
     for (size_t q = 0; q < best.n; ++q) tids[q] = tax_seq_to_tax(&idx->tax, best.a[q]);
     uint64_t out[ORA_MAX_MATCH];
-    int n = ora_tax_reduce(&idx->tax, tids, (int)best.n, P->maxResult, out, ORA_MAX_MATCH);
+    u64vec child[ORA_MAX_MATCH];
+    int nchild = 0;
+    memset(child, 0, sizeof(child));
+    int n = tax_reduce(&idx->tax, tids, (int)best.n, P->maxResult, out, ORA_MAX_MATCH, P->outputExpandedResult ? child : NULL, &nchild);
     for (int q = 0; q < n; ++q) {
       result->kind[q] = 1; result->id[q] = out[q];
       result->taxid[q] = tax_orig(&idx->tax, out[q]);
     }
+    if (P->outputExpandedResult && nchild == n) {          /* :821-839: only when one list per promoted id came back */
+      size_t total = 0;
+      for (int q = 0; q < n; ++q) total += child[q].n;
+      result->expanded = xmalloc((total ? total : 1) * 8);
+      size_t at = 0;
+      for (int q = 0; q < n; ++q) {
+        result->expOff[q] = (int32_t)at;
+        for (size_t j = 0; j < child[q].n; ++j) result->expanded[at++] = tax_orig(&idx->tax, child[q].a[j]);   /* GetOrigTaxId (:833) */
+      }
+      for (int q = n; q <= ORA_MAX_MATCH; ++q) result->expOff[q] = (int32_t)at;
+    }
+    for (int q = 0; q < ORA_MAX_MATCH; ++q) free(child[q].a);
     result->nmatch = n;
     free(tids);
   }
@@ -1234,20 +1299,35 @@ void ora_classify_batch(const ora_index *idx, const uint8_t *bases1, const uint6
 const char *ora_tsv_header(void) {   /* ResultWriter::OutputHeader (ResultWriter.hpp:186-197) */
   return "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\n";
 }
+const char *ora_tsv_header_for(const ora_index *idx) {   /* ... with the expandedTaxIDs column of --expand-taxid (:194-195) */
+  return idx->param.outputExpandedResult
+           ? "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\texpandedTaxIDs\n" : ora_tsv_header();
+}
+void ora_results_free(ora_result *r, size_t n) {
+  for (size_t i = 0; i < n; ++i) { free(r[i].expanded); r[i].expanded = NULL; }
+}
 /* ResultWriter::Output (ResultWriter.hpp:199-242) */
 size_t ora_format_result(const ora_index *idx, const char *readid, const ora_result *r, char *buf, size_t cap) {
   size_t off = 0;
+  const int expand = idx->param.outputExpandedResult;
+#define ORA_PUT(...) { int w_ = snprintf(buf ? buf + off : NULL, buf && cap > off ? cap - off : 0, __VA_ARGS__); off += (size_t)w_; }
   if (r->nmatch > 0) {
     for (int i = 0; i < r->nmatch; ++i) {
       const char *name = r->kind[i] == 0 ? idx->tax.seqName[r->id[i]] : ora_tax_rank_string(tax_rank(&idx->tax, r->id[i]));
-      int w = snprintf(buf ? buf + off : NULL, buf && cap > off ? cap - off : 0, "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d\n",
-                       readid, name, (unsigned long)r->taxid[i], (unsigned long)r->score, (unsigned long)r->secondaryScore,
-                       r->hitLength, r->queryLength, r->nmatch);
-      off += (size_t)w;
+      ORA_PUT("%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d", readid, name, (unsigned long)r->taxid[i], (unsigned long)r->score,
+              (unsigned long)r->secondaryScore, r->hitLength, r->queryLength, r->nmatch);
+      if (expand) {                                        /* PrintExtraCol(expandedTaxIdStrings[i]) (:226-227) */
+        ORA_PUT("\t");
+        if (r->expanded)
+          for (int32_t j = r->expOff[i]; j < r->expOff[i + 1]; ++j) ORA_PUT(j == r->expOff[i] ? "%lu" : ",%lu", (unsigned long)r->expanded[j]);
+      }
+      ORA_PUT("\n");
     }
   } else {
-    int w = snprintf(buf ? buf + off : NULL, buf && cap > off ? cap - off : 0, "%s\tunclassified\t0\t0\t0\t0\t%d\t1\n", readid, r->queryLength);
-    off += (size_t)w;
+    ORA_PUT("%s\tunclassified\t0\t0\t0\t0\t%d\t1", readid, r->queryLength);
+    if (expand) ORA_PUT("\t");
+    ORA_PUT("\n");
   }
+#undef ORA_PUT
   return off;
 }

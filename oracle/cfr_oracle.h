@@ -127,6 +127,7 @@ typedef struct {
   int maxResultPerHitFactor;   /* 40 */
   uint64_t considerSecondaryHitLen;     /* 2000 */
   double considerSecondaryScoreFactor;  /* 0.995 */
+  int outputExpandedResult;    /* --expand-taxid (Classifier.hpp:22): keep the children that ReduceTaxIds promoted */
 } ora_param;
 
 typedef struct {
@@ -163,6 +164,11 @@ typedef struct {
   int32_t kind[ORA_MAX_MATCH];
   uint64_t id[ORA_MAX_MATCH];
   uint64_t taxid[ORA_MAX_MATCH];   /* ORIGINAL tax id printed in column 3 */
+  /* --expand-taxid (Classifier.hpp:49, 792-838): ORIGINAL tax ids of the children promoted into match i =
+   * expanded[expOff[i] .. expOff[i+1]); expanded == NULL when every string is empty.  malloc'ed by the classification,
+   * released by ora_results_free (a result must start zeroed: calloc / ctypes arrays do). */
+  uint64_t *expanded;
+  int32_t expOff[ORA_MAX_MATCH + 1];
 } ora_result;
 
 /* default parameter block (Classifier.hpp:28-37) */
@@ -223,6 +229,8 @@ size_t ora_query_hits(const ora_index *idx, const char *r1, const char *r2, ora_
 /* TSV (ResultWriter.hpp:186-242).  returns bytes written into buf (needs cap) or required size */
 size_t ora_format_result(const ora_index *idx, const char *readid, const ora_result *r, char *buf, size_t cap);
 const char *ora_tsv_header(void);
+const char *ora_tsv_header_for(const ora_index *idx);   /* with the expandedTaxIDs column when the index was loaded with outputExpandedResult */
+void ora_results_free(ora_result *r, size_t n);
 const char *ora_tax_rank_string(uint8_t rank);
 
 /* taxonomy helpers exposed for tests */

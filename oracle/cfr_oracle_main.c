@@ -1,7 +1,7 @@
 /*
  * cfr_oracle_main.c — TEST INFRASTRUCTURE: command-line front end of the CPU restatement.
  *
- *   cfr_oracle classify -x IDX (-u R | -1 R1 -2 R2) [-k K] [-t T] [--no-dust] [--min-hitlen N] [--hitk-factor N]
+ *   cfr_oracle classify -x IDX (-u R | -1 R1 -2 R2) [-k K] [-t T] [--no-dust] [--min-hitlen N] [--hitk-factor N] [--expand-taxid]
  *        -> TSV on stdout, same bytes as the reference `centrifuger` (ResultWriter.hpp:186-242)
  *   cfr_oracle dump-rank   -x IDX [--step S]     -> "i acc rA rC rG rT eA eC eG eT" (FMIndex::Rank incl/excl, Access)
  *   cfr_oracle dump-bs     -x IDX -u R           -> per read/strand/prefix: "l sp ep"
@@ -80,6 +80,7 @@ int main(int argc, char **argv) {
     else if (!strcmp(argv[i], "-k")) P.maxResult = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-t")) threads = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--no-dust")) dust = 0;
+    else if (!strcmp(argv[i], "--expand-taxid")) P.outputExpandedResult = 1;
     else if (!strcmp(argv[i], "--min-hitlen")) P.minHitLen = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--hitk-factor")) P.maxResultPerHitFactor = atoi(argv[++i]);
     else if (!strcmp(argv[i], "--step")) step = strtoull(argv[++i], NULL, 10);
@@ -133,7 +134,7 @@ int main(int argc, char **argv) {
   ora_counters cnt;
   ora_classify_batch(idx, r1.bases, r1.offs, m2 ? r2.bases : NULL, m2 ? r2.offs : NULL, r1.n, dust, threads, res, &cnt);
   if (!strcmp(cmd, "classify")) {
-    fputs(ora_tsv_header(), stdout);
+    fputs(ora_tsv_header_for(idx), stdout);
     char buf[1 << 16];
     for (size_t i = 0; i < r1.n; ++i) {
       size_t w = ora_format_result(idx, r1.id[i], &res[i], buf, sizeof(buf));
@@ -145,6 +146,7 @@ int main(int argc, char **argv) {
            (unsigned long)cnt.filter, (unsigned long)cnt.hits, (unsigned long)cnt.bs_calls, (unsigned long)cnt.extends,
            (unsigned long)cnt.lf_steps, (unsigned long)cnt.locates, (unsigned long)cnt.read_bases);
   } else { fprintf(stderr, "unknown command %s\n", cmd); return 1; }
+  ora_results_free(res, r1.n);
   free(res);
   ora_index_free(idx);
   return 0;

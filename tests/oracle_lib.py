@@ -12,13 +12,21 @@ ORA_MAX_MATCH = 64
 
 class OraParam(C.Structure):
     _fields_ = [("maxResult", C.c_int), ("minHitLen", C.c_int), ("maxResultPerHitFactor", C.c_int),
-                ("considerSecondaryHitLen", C.c_uint64), ("considerSecondaryScoreFactor", C.c_double)]
+                ("considerSecondaryHitLen", C.c_uint64), ("considerSecondaryScoreFactor", C.c_double),
+                ("outputExpandedResult", C.c_int)]
 
 
 class OraResult(C.Structure):
     _fields_ = [("score", C.c_uint64), ("secondaryScore", C.c_uint64), ("hitLength", C.c_int32), ("queryLength", C.c_int32),
                 ("nmatch", C.c_int32), ("kind", C.c_int32 * ORA_MAX_MATCH), ("id", C.c_uint64 * ORA_MAX_MATCH),
-                ("taxid", C.c_uint64 * ORA_MAX_MATCH)]
+                ("taxid", C.c_uint64 * ORA_MAX_MATCH),
+                ("expanded", C.POINTER(C.c_uint64)), ("expOff", C.c_int32 * (ORA_MAX_MATCH + 1))]
+
+    def expanded_ids(self, q):
+        """--expand-taxid: the ORIGINAL tax ids promoted into match q (Classifier.hpp:821-839)"""
+        if not self.expanded:
+            return []
+        return [int(self.expanded[j]) for j in range(self.expOff[q], self.expOff[q + 1])]
 
 
 class OraCounters(C.Structure):
@@ -74,13 +82,15 @@ def lib():
         L.ora_format_result.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p, C.c_size_t]
         L.ora_dust_mask_inplace.argtypes = [C.c_char_p, C.c_size_t]
         L.ora_tsv_header.restype = C.c_char_p
+        L.ora_tsv_header_for.restype = C.c_char_p
+        L.ora_tsv_header_for.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
 
 class OracleIndex:
-    def __init__(self, prefix, max_result=1, min_hit_len=0, hitk_factor=40):
-        p = OraParam(max_result, min_hit_len, hitk_factor, 2000, 0.995)
+    def __init__(self, prefix, max_result=1, min_hit_len=0, hitk_factor=40, expand=False):
+        p = OraParam(max_result, min_hit_len, hitk_factor, 2000, 0.995, int(expand))
         self.param = p
         self._h = lib().ora_index_load(prefix.encode(), C.addressof(p))
         if not self._h:
@@ -138,7 +148,7 @@ class OracleIndex:
         return buf.raw[:n]
 
     def tsv(self, ids, results) -> bytes:
-        return lib().ora_tsv_header() + b"".join(self.format(i, results[k]) for k, i in enumerate(ids))
+        return lib().ora_tsv_header_for(self._h) + b"".join(self.format(i, results[k]) for k, i in enumerate(ids))
 
 
 def dust_mask(s: bytes) -> bytes:
