@@ -24,7 +24,7 @@ class CfrError(RuntimeError):
 
 class Params(C.Structure):
     _fields_ = [("max_result", C.c_int32), ("min_hit_len", C.c_int32), ("max_result_per_hit_factor", C.c_int32),
-                ("reserved", C.c_int32), ("consider_secondary_hit_len", C.c_uint64),
+                ("output_expanded", C.c_int32), ("consider_secondary_hit_len", C.c_uint64),
                 ("consider_secondary_score_factor", C.c_double)]
 
 
@@ -44,6 +44,7 @@ HIT_DTYPE = np.dtype([("sp", "<u8"), ("ep", "<u8"), ("l", "<i4"), ("strand", "<i
 RESULT_DTYPE = np.dtype([("score", "<u8"), ("secondary_score", "<u8"), ("hit_length", "<i4"), ("query_length", "<i4"),
                          ("n_match", "<i4"), ("pad", "<i4"), ("match_begin", "<u8")])
 MATCH_DTYPE = np.dtype([("id", "<u8"), ("taxid", "<u8"), ("kind", "<i4"), ("pad", "<i4")])
+SPAN_DTYPE = np.dtype([("begin", "<u8"), ("count", "<u8")])      # cfr_span: the --expand-taxid list of a match slot
 # the narrow layout of cfr_classify_batch_resident_compact (20 + 12 bytes)
 RESULT_COMPACT_DTYPE = np.dtype([("score", "<u4"), ("secondary_score", "<u4"), ("hit_length", "<u4"), ("query_length", "<u4"),
                                  ("n_match", "u1"), ("flags", "u1"), ("pad", "<u2")])
@@ -91,6 +92,7 @@ EXPORTS = [
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
     "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest", "cfr_pack_reads", "cfr_classify_batch_packed",
+    "cfr_classify_batch_expanded", "cfr_classify_from_hits_expanded", "cfr_format_tsv_expanded", "cfr_tsv_header_expanded",
 ]
 
 _lib = None
@@ -106,11 +108,13 @@ def lib():
         L.cfr_version.restype = C.c_char_p
         L.cfr_tsv_header.restype = C.c_char_p
         L.cfr_format_tsv.restype = C.c_size_t
+        L.cfr_format_tsv_expanded.restype = C.c_size_t
+        L.cfr_tsv_header_expanded.restype = C.c_char_p
         L.cfr_host_alloc.restype = C.c_void_p
         L.cfr_host_alloc.argtypes = [C.c_size_t]
         L.cfr_host_free.argtypes = [C.c_void_p]
         for name in EXPORTS:
-            if name not in ("cfr_last_error", "cfr_version", "cfr_tsv_header", "cfr_format_tsv", "cfr_index_destroy",
+            if name not in ("cfr_last_error", "cfr_version", "cfr_tsv_header", "cfr_format_tsv", "cfr_index_destroy", "cfr_format_tsv_expanded", "cfr_tsv_header_expanded",
                             "cfr_device_index_destroy", "cfr_params_default", "cfr_host_alloc", "cfr_host_free", "cfr_build_options_default"):
                 getattr(L, name).restype = C.c_int
         _lib = L
@@ -239,6 +243,38 @@ class Index:
             buf = C.create_string_buffer(n + 1)
             lib().cfr_format_tsv(self._h, read_id.encode(), _p(r), _p(matches), buf, C.c_size_t(len(buf)))
         return buf.raw[:n]
+
+    def format_tsv_expanded(self, read_id: str, result, matches, spans, ids) -> bytes:
+        """cfr_format_tsv_expanded: the row(s) of one read with the expandedTaxIDs column"""
+        r = np.ascontiguousarray(result).reshape(1)
+        buf = C.create_string_buffer(1 << 16)
+        n = lib().cfr_format_tsv_expanded(self._h, read_id.encode(), _p(r), _p(matches), _p(spans), _p(ids), buf, C.c_size_t(len(buf)))
+        if n >= len(buf):
+            buf = C.create_string_buffer(n + 1)
+            lib().cfr_format_tsv_expanded(self._h, read_id.encode(), _p(r), _p(matches), _p(spans), _p(ids), buf, C.c_size_t(len(buf)))
+        return buf.raw[:n]
+
+    def classify_from_hits_expanded(self, hits, hit_begin, row_begin, row_vals, query_len, threads=1):
+        """cfr_classify_from_hits_expanded -> (results, matches, spans, ids)"""
+        n = len(hit_begin) - 1
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        hit_begin, row_begin, row_vals = _u64(hit_begin), _u64(row_begin), _u64(row_vals)
+        query_len = np.ascontiguousarray(query_len, dtype=np.int32)
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        cap, icap = max(16, 4 * n), max(16, 4 * n)
+        while True:
+            matches = np.zeros(cap, dtype=MATCH_DTYPE)
+            spans = np.zeros(cap, dtype=SPAN_DTYPE)
+            ids = np.zeros(icap, dtype=np.uint64)
+            nm, ni = C.c_size_t(0), C.c_size_t(0)
+            st = lib().cfr_classify_from_hits_expanded(self._h, _p(hits), _p(hit_begin), _p(row_begin), _p(row_vals), _p(query_len),
+                                                       C.c_size_t(n), C.c_int(threads), _p(results), _p(matches), _p(spans), C.c_size_t(cap),
+                                                       C.byref(nm), _p(ids), C.c_size_t(icap), C.byref(ni))
+            if st == CFR_ERR_CAPACITY:
+                cap, icap = max(cap, int(nm.value) + 16), max(icap, int(ni.value) + 16)
+                continue
+            _check(st)
+            return results, matches[:nm.value], spans[:nm.value], ids[:ni.value]
 
     def classify_from_hits(self, hits, hit_begin, row_begin, row_vals, query_len, threads=1):
         n = len(hit_begin) - 1
@@ -384,6 +420,26 @@ class DeviceIndex:
                 continue
             _check(st)
             return results, matches[:nm.value]
+
+    def classify_expanded(self, bases1, offsets1, bases2=None, offsets2=None, ids_cap=None):
+        """cfr_classify_batch_expanded (the index must have been opened with output_expanded=1) -> (results, matches, spans, ids)"""
+        bases1, offsets1, bases2, offsets2 = _u8(bases1), _u64(offsets1), _u8(bases2), _u64(offsets2)
+        n = len(offsets1) - 1
+        results = np.zeros(n, dtype=RESULT_DTYPE)
+        cap = max(16, max(1, self.index.params.max_result) * n)
+        icap = ids_cap if ids_cap is not None else max(16, 4 * n)
+        while True:
+            matches = np.zeros(cap, dtype=MATCH_DTYPE)
+            spans = np.zeros(cap, dtype=SPAN_DTYPE)
+            ids = np.zeros(max(icap, 1), dtype=np.uint64)
+            nm, ni = C.c_size_t(0), C.c_size_t(0)
+            st = lib().cfr_classify_batch_expanded(self._d, _p(bases1), _p(offsets1), _p(bases2), _p(offsets2), C.c_size_t(n), _p(results), _p(matches),
+                                                   _p(spans), C.c_size_t(cap), C.byref(nm), _p(ids), C.c_size_t(icap), C.byref(ni))
+            if st == CFR_ERR_CAPACITY:
+                cap, icap = max(cap, int(nm.value) + 16), max(icap, int(ni.value))
+                continue
+            _check(st)
+            return results, matches[:nm.value], spans[:nm.value], ids[:ni.value]
 
     def classify_packed(self, packed1, offsets1, packed2=None, offsets2=None, results=None, matches=None):
         """cfr_classify_batch_packed: the bases as packed blocks (pack_reads) instead of ASCII; same results as classify()"""

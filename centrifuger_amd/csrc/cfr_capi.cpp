@@ -106,7 +106,7 @@ int default_tail_threads() {
 extern "C" {
 
 void cfr_params_default(cfr_params *p) {   // _classifierParam() (Classifier.hpp:28-37)
-  p->max_result = 1; p->min_hit_len = 0; p->max_result_per_hit_factor = 40; p->reserved = 0;
+  p->max_result = 1; p->min_hit_len = 0; p->max_result_per_hit_factor = 40; p->output_expanded = 0;
   p->consider_secondary_hit_len = 2000; p->consider_secondary_score_factor = 0.995;
 }
 const char *cfr_last_error(void) { return g_err.c_str(); }
@@ -277,6 +277,43 @@ cfr_status cfr_classify_batch(cfr_dev_index *d, const uint8_t *bases1, const uin
   });
 }
 
+// --expand-taxid: the records the tail appended (slot, count, ids ...) in whatever order its atomics fell, made into spans over an id
+// array in match-slot order.  A sub-batch that ran twice (scratch pool too small the first time) left two records for a slot, with
+// the same ids: the last one counts.
+static cfr_status expanded_out(const std::vector<uint64_t> &raw, cfr_span *spans, size_t match_cap, uint64_t *ids, size_t ids_cap, size_t *n_ids) {
+  for (size_t m = 0; m < match_cap; ++m) spans[m] = cfr_span{0, 0};
+  std::vector<std::pair<uint64_t, size_t>> recs;             // (slot, position of the record)
+  for (size_t at = 0; at + 2 <= raw.size(); at += 2 + (size_t)raw[at + 1]) recs.emplace_back(raw[at], at);
+  std::stable_sort(recs.begin(), recs.end(), [](const std::pair<uint64_t, size_t> &a, const std::pair<uint64_t, size_t> &b) { return a.first < b.first; });
+  size_t need = 0;
+  for (size_t j = 0; j < recs.size(); ++j) if (j + 1 == recs.size() || recs[j + 1].first != recs[j].first) need += (size_t)raw[recs[j].second + 1];
+  if (n_ids) *n_ids = need;
+  if (need > ids_cap) { g_err = "cfr_classify_batch_expanded: id buffer too small"; return CFR_ERR_CAPACITY; }
+  size_t out = 0;
+  for (size_t j = 0; j < recs.size(); ++j) {
+    if (j + 1 < recs.size() && recs[j + 1].first == recs[j].first) continue;
+    const size_t at = recs[j].second, cnt = (size_t)raw[at + 1];
+    if (recs[j].first >= match_cap) { g_err = "cfr_classify_batch_expanded: a list for a match slot outside the match buffer"; return CFR_ERR_HIP; }
+    spans[recs[j].first] = cfr_span{out, cnt};
+    memcpy(ids + out, raw.data() + at + 2, cnt * 8);
+    out += cnt;
+  }
+  return CFR_OK;
+}
+
+cfr_status cfr_classify_batch_expanded(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1, const uint8_t *bases2,
+                                       const uint64_t *offsets2, size_t n, cfr_result *results, cfr_match *matches, cfr_span *spans,
+                                       size_t match_cap, size_t *n_matches, uint64_t *ids, size_t ids_cap, size_t *n_ids) {
+  if (!d || (n && (!bases1 || !offsets1 || !results)) || (match_cap && !spans) || (ids_cap && !ids)) return bad_arg("cfr_classify_batch_expanded: null argument");
+  if ((bases2 == nullptr) != (offsets2 == nullptr)) return bad_arg("cfr_classify_batch_expanded: bases2/offsets2 must both be given");
+  if (!d->d->host().params.output_expanded) return bad_arg("cfr_classify_batch_expanded: the index was opened without cfr_params.output_expanded");
+  CFR_ENTER(d, "cfr_classify_batch_expanded");
+  return guarded([&]() -> cfr_status {
+    d->d->classify_host(bases1, offsets1, bases2, offsets2, n, results, matches, match_cap, n_matches);
+    return expanded_out(d->d->expanded_raw_, spans, match_cap, ids, ids_cap, n_ids);
+  });
+}
+
 // cfr_pack_reads: the packed form of a read buffer (what k_pack_reads makes on the device), on host threads
 cfr_status cfr_pack_reads(const uint8_t *bases, uint64_t total, int threads, uint64_t *packed) {
   if ((total && !bases) || !packed) return bad_arg("cfr_pack_reads: null argument");
@@ -428,6 +465,34 @@ cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, con
   });
 }
 
+cfr_status cfr_classify_from_hits_expanded(const cfr_index *idx, const cfr_hit *hits, const uint64_t *hit_begin, const uint64_t *row_begin,
+                                           const uint64_t *row_vals, const int32_t *query_len, size_t n, int threads, cfr_result *results,
+                                           cfr_match *matches, cfr_span *spans, size_t match_cap, size_t *n_matches, uint64_t *ids, size_t ids_cap,
+                                           size_t *n_ids) {
+  if (!idx || !hit_begin || (n && (!results || !query_len)) || (match_cap && !spans) || (ids_cap && !ids)) return bad_arg("cfr_classify_from_hits_expanded: null argument");
+  if (!idx->h->params.output_expanded) return bad_arg("cfr_classify_from_hits_expanded: the index was opened without cfr_params.output_expanded");
+  return guarded([&]() -> cfr_status {
+    cfr::DeviceIndex::BatchOut out;
+    out.hit_begin.assign(hit_begin, hit_begin + n + 1);
+    const uint64_t nh = hit_begin[n];
+    out.hits.assign(hits, hits + nh);
+    out.row_begin.assign(row_begin, row_begin + nh + 1);
+    out.row_vals.assign(row_vals, row_vals + row_begin[nh]);
+    out.read_len.assign(query_len, query_len + n);
+    std::vector<cfr_match> mv;
+    cfr::ExpandedLists x;
+    cfr::classify_batch_tail(*idx->h, out, n, threads, results, mv, &x);
+    if (n_matches) *n_matches = mv.size();
+    if (n_ids) *n_ids = x.ids.size();
+    if (mv.size() > match_cap) { g_err = "cfr_classify_from_hits_expanded: match buffer too small"; return CFR_ERR_CAPACITY; }
+    if (x.ids.size() > ids_cap) { g_err = "cfr_classify_from_hits_expanded: id buffer too small"; return CFR_ERR_CAPACITY; }
+    if (!mv.empty()) memcpy(matches, mv.data(), mv.size() * sizeof(cfr_match));
+    for (size_t m = 0; m < match_cap; ++m) spans[m] = m < x.spans.size() ? x.spans[m] : cfr_span{0, 0};
+    if (!x.ids.empty()) memcpy(ids, x.ids.data(), x.ids.size() * 8);
+    return CFR_OK;
+  });
+}
+
 cfr_status cfr_last_batch_stats(const cfr_dev_index *d, cfr_batch_stats *st) {
   if (!d || !st) return bad_arg("cfr_last_batch_stats: null argument");
   *st = d->d->last_stats;
@@ -476,8 +541,23 @@ const char *cfr_tsv_header(void) {   // ResultWriter::OutputHeader (ResultWriter
   return "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\n";
 }
 
+const char *cfr_tsv_header_expanded(void) {   // ... with _outputExpandedTaxIds (ResultWriter.hpp:194-195)
+  return "readID\tseqID\ttaxID\tscore\t2ndBestScore\thitLength\tqueryLength\tnumMatches\texpandedTaxIDs\n";
+}
+
+static size_t format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, bool expanded, const cfr_span *spans,
+                         const uint64_t *ids, char *buf, size_t cap);
 size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, char *buf, size_t cap) {
-  // ResultWriter::Output (ResultWriter.hpp:209-240)
+  return format_tsv(idx, read_id, r, matches, false, nullptr, nullptr, buf, cap);
+}
+size_t cfr_format_tsv_expanded(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, const cfr_span *spans,
+                               const uint64_t *ids, char *buf, size_t cap) {
+  return format_tsv(idx, read_id, r, matches, true, spans, ids, buf, cap);
+}
+
+static size_t format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, bool expanded, const cfr_span *spans,
+                         const uint64_t *ids, char *buf, size_t cap) {
+  // ResultWriter::Output (ResultWriter.hpp:209-240); expanded: PrintExtraCol(expandedTaxIdStrings[i]) / PrintExtraCol("") (:226-227, :239-240)
   size_t off = 0;
   auto put = [&](int w) { if (w > 0) off += (size_t)w; };
   const cfr::Taxonomy &t = idx->h->tax;
@@ -487,13 +567,20 @@ size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_resul
       const char *name;
       if (m.kind == 0) name = m.id < t.seq_name.size() ? t.seq_name[m.id].c_str() : "";
       else name = cfr::tax_rank_string(m.id < t.node_cnt ? t.rank[m.id] : 0);
-      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d\n", read_id,
+      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d", read_id,
                    name, (unsigned long)m.taxid, (unsigned long)r->score, (unsigned long)r->secondary_score, r->hit_length,
                    r->query_length, r->n_match));
+      if (expanded) {
+        put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "\t"));
+        const cfr_span sp = spans ? spans[r->match_begin + (uint64_t)i] : cfr_span{0, 0};
+        for (uint64_t j = 0; j < sp.count; ++j)
+          put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, j ? ",%lu" : "%lu", (unsigned long)ids[sp.begin + j]));
+      }
+      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "\n"));
     }
   } else {
-    put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\tunclassified\t0\t0\t0\t0\t%d\t1\n", read_id,
-                 r->query_length));
+    put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, expanded ? "%s\tunclassified\t0\t0\t0\t0\t%d\t1\t\n" : "%s\tunclassified\t0\t0\t0\t0\t%d\t1\n",
+                 read_id, r->query_length));
   }
   return off;
 }

@@ -7,7 +7,7 @@
 // cfr_classify_batch call per batch here; batches round-robin over the GPUs given by --gpu, output stays
 // in input order.  Additive options: --gpu LIST|all, --gpu-batch N, --gpu-throughput.
 // Options of the reference that are outside this build (barcode/UMI/read-format/sample-sheet/
-// merge-readpair/expand-taxid) are rejected with a message instead of being silently ignored.
+// merge-readpair) are rejected with a message instead of being silently ignored.
 #include <fcntl.h>
 #include <getopt.h>
 #include <cerrno>
@@ -54,6 +54,7 @@ const char *kUsage =
     "\t--min-hitlen INT: minimum length of partial hits [auto]\n"
     "\t--hitk-factor INT: resolve at most <int>*k entries for each hit [40; use 0 for no restriction]\n"
     "\t--consider-secondary STR: in the format INT,FLOAT consider the secondary hit if its hitlen>=INT,score>=FLOAT*best_score [2000,0.995]\n"
+    "\t--expand-taxid: output the tax IDs that are promoted to the final report tax ID [no]\n"
     "\t--gpu LIST: comma separated MI355X ordinals, or 'all' [0]\n"
     "\t--gpu-batch INT: reads per device batch [262144]\n"
     "\t--gpu-balanced: also derive the text-mode tables and the locate memo on the device (+0.4 s load per Gbp, faster kernels)\n"
@@ -62,7 +63,7 @@ const char *kUsage =
     "\t-h: print this usage message\n"
     "\t-v: print the version information and quit\n";
 
-enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_GPU_THROUGHPUT, OPT_GPU_FASTLOAD, OPT_GPU_BALANCED, OPT_PARSE_THREADS, OPT_UNSUPPORTED };
+enum { OPT_UN = 1000, OPT_CL, OPT_NO_DUST, OPT_MIN_HITLEN, OPT_HITK, OPT_SECONDARY, OPT_GPU, OPT_GPU_BATCH, OPT_GPU_THROUGHPUT, OPT_GPU_FASTLOAD, OPT_GPU_BALANCED, OPT_PARSE_THREADS, OPT_EXPAND_TAXID, OPT_UNSUPPORTED };
 
 void print_log(const char *fmt, ...) {   // Utils::PrintLog (compactds/Utils.hpp:369-381)
   char buffer[1024];
@@ -437,6 +438,8 @@ struct Batch {
   std::vector<uint64_t> offs1, offs2;
   std::vector<cfr_result> results;
   std::vector<cfr_match> matches;
+  std::vector<cfr_span> spans;         // --expand-taxid: per match slot, its list in exp_ids
+  std::vector<uint64_t> exp_ids;
   std::string tsv;
   bool done = false;
   const char *id(size_t i) const { return ids.data() + id_off[i]; }
@@ -565,7 +568,7 @@ int main(int argc, char *argv[]) {
       {"gpu-fast-load", no_argument, 0, OPT_GPU_FASTLOAD}, {"gpu-balanced", no_argument, 0, OPT_GPU_BALANCED},
       {"parse-threads", required_argument, 0, OPT_PARSE_THREADS},
       {"sample-sheet", required_argument, 0, OPT_UNSUPPORTED}, {"merge-readpair", no_argument, 0, OPT_UNSUPPORTED},
-      {"expand-taxid", no_argument, 0, OPT_UNSUPPORTED}, {"read-format", required_argument, 0, OPT_UNSUPPORTED},
+      {"expand-taxid", no_argument, 0, OPT_EXPAND_TAXID}, {"read-format", required_argument, 0, OPT_UNSUPPORTED},
       {"barcode", required_argument, 0, OPT_UNSUPPORTED}, {"UMI", required_argument, 0, OPT_UNSUPPORTED},
       {"barcode-whitelist", required_argument, 0, OPT_UNSUPPORTED}, {"barcode-translate", required_argument, 0, OPT_UNSUPPORTED},
       {0, 0, 0, 0}};
@@ -584,6 +587,7 @@ int main(int argc, char *argv[]) {
       case OPT_UN: opt.un_prefix = optarg; break;
       case OPT_CL: opt.cl_prefix = optarg; break;
       case OPT_NO_DUST: opt.dust = false; break;
+      case OPT_EXPAND_TAXID: opt.params.output_expanded = 1; break;       // CentrifugerClass.cpp:453-455
       case OPT_MIN_HITLEN: opt.params.min_hit_len = atoi(optarg); break;
       case OPT_HITK: opt.params.max_result_per_hit_factor = atoi(optarg); break;
       case OPT_SECONDARY: {
@@ -1049,7 +1053,8 @@ int main(int argc, char *argv[]) {
     devs.push_back(d);
   }
   clk.add(T_DEVICE, t0);
-  fputs(cfr_tsv_header(), stdout);          // only once the index and the devices are up: a failed load prints no TSV at all
+  const bool expand = opt.params.output_expanded != 0;
+  fputs(expand ? cfr_tsv_header_expanded() : cfr_tsv_header(), stdout);          // only once the index and the devices are up: a failed load prints no TSV at all
 
 
   // device stage: one thread per GPU takes dust-masked batches
@@ -1066,11 +1071,20 @@ int main(int argc, char *argv[]) {
       const auto ts = tick();
       b->results.resize(b->n);
       size_t cap = b->n * (size_t)(opt.params.max_result > 0 ? opt.params.max_result : 4) + 16, used = 0;
+      size_t ids_cap = expand ? std::max<size_t>(b->exp_ids.size(), 4 * b->n + 16) : 0, ids_used = 0;
       for (;;) {
         b->matches.resize(cap);
-        cfr_status s = cfr_classify_batch(dev, b->bases1.data(), b->offs1.data(), b->paired ? b->bases2.data() : nullptr,
-                                          b->paired ? b->offs2.data() : nullptr, b->n, b->results.data(), b->matches.data(), cap, &used);
-        if (s == CFR_ERR_CAPACITY) { cap = used + 16; continue; }
+        cfr_status s;
+        if (expand) {
+          b->spans.resize(cap);
+          b->exp_ids.resize(ids_cap);
+          s = cfr_classify_batch_expanded(dev, b->bases1.data(), b->offs1.data(), b->paired ? b->bases2.data() : nullptr,
+                                          b->paired ? b->offs2.data() : nullptr, b->n, b->results.data(), b->matches.data(), b->spans.data(), cap, &used,
+                                          b->exp_ids.data(), ids_cap, &ids_used);
+        } else
+        s = cfr_classify_batch(dev, b->bases1.data(), b->offs1.data(), b->paired ? b->bases2.data() : nullptr,
+                               b->paired ? b->offs2.data() : nullptr, b->n, b->results.data(), b->matches.data(), cap, &used);
+        if (s == CFR_ERR_CAPACITY) { if (used > cap) cap = used + 16; if (ids_used > ids_cap) ids_cap = ids_used + 16; continue; }
         if (s != CFR_OK) die_status("cfr_classify_batch", s);
         break;
       }
@@ -1105,12 +1119,16 @@ int main(int argc, char *argv[]) {
         std::string &out = parts[(size_t)t];
         out.reserve((hi - lo) * 96);
         char buf[8192];
+        auto row = [&](size_t i, char *dst, size_t cap) {
+          return expand ? cfr_format_tsv_expanded(idx, b->id(i), &b->results[i], b->matches.data(), b->spans.data(), b->exp_ids.data(), dst, cap)
+                        : cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), dst, cap);
+        };
         for (size_t i = lo; i < hi; ++i) {
-          size_t w = cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), buf, sizeof(buf));
+          size_t w = row(i, buf, sizeof(buf));
           if (w < sizeof(buf)) out.append(buf, w);
           else {
             std::string big(w + 1, '\0');
-            cfr_format_tsv(idx, b->id(i), &b->results[i], b->matches.data(), &big[0], big.size());
+            row(i, &big[0], big.size());
             out.append(big.data(), w);
           }
         }

@@ -37,7 +37,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_COUNT
 };
 
 }  // namespace
@@ -1226,6 +1226,34 @@ std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool pe
   return pieces;
 }
 
+// --expand-taxid: the lists leave through a pool of the image (exp_append).  Its size is a guess that the workload corrects: a call
+// whose records did not fit is run again with a pool that holds them (the cursor counts on past the end), and the size is kept.
+void DeviceIndex::expand_begin() {
+  expanded_raw_.clear();
+  if (!host_->params.output_expanded) return;
+  if (!exp_cap_) {
+    exp_cap_ = 1ull << 20;
+    if (const char *e = dbg_env("CFR_EXP_POOL_INIT")) exp_cap_ = std::max<uint64_t>(4, strtoull(e, nullptr, 10));    // test hook: a pool that has to grow
+  }
+  uint64_t *pool = (uint64_t *)scratch(S_EXPPOOL, exp_cap_ * 8);
+  unsigned long long *cur = (unsigned long long *)scratch(S_EXPCUR, 8);
+  HIP_CHECK(hipMemsetAsync(cur, 0, 8, stream_));
+  if (view_.exp_pool != pool || view_.exp_cursor != cur || view_.exp_cap != exp_cap_) {
+    view_.exp_pool = pool; view_.exp_cursor = cur; view_.exp_cap = exp_cap_;
+    HIP_CHECK(hipMemcpyAsync(d_view_, &view_, sizeof(DevView), hipMemcpyHostToDevice, stream_));
+  }
+  HIP_CHECK(hipStreamSynchronize(stream_));                // (the post stage may run on another stream)
+}
+bool DeviceIndex::expand_end() {
+  if (!host_->params.output_expanded) return true;
+  unsigned long long used = 0;
+  HIP_CHECK(hipMemcpy(&used, view_.exp_cursor, 8, hipMemcpyDeviceToHost));
+  if (used > exp_cap_) { exp_cap_ = (uint64_t)used + (uint64_t)used / 4 + 1024; return false; }
+  expanded_raw_.resize((size_t)used);
+  if (used) HIP_CHECK(hipMemcpy(expanded_raw_.data(), view_.exp_pool, (size_t)used * 8, hipMemcpyDeviceToHost));
+  return true;
+}
+
 void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, const uint8_t *d_b2, const uint64_t *d_o2, size_t n,
                                   uint64_t total1, uint64_t total2, cfr_result *results, cfr_match *matches, size_t match_cap,
                                   size_t *match_extent, const HostSrc *src, bool compact) {
@@ -1233,7 +1261,9 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   last_stats = cfr_batch_stats{};
   pre_hit_off_ = nullptr;
   if (match_extent) *match_extent = 0;
+  expanded_raw_.clear();
   if (n == 0) return;
+  expand_begin();
   prot_total1_ = total1; prot_total2_ = total2; prot_o1_base_ = d_o1; prot_reads_ = n;
   const uint64_t stride = view_.max_result > 0 ? (uint64_t)view_.max_result : 0;
   if (stride && match_extent) *match_extent = stride * n;
@@ -1607,6 +1637,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     last_stats.total_ms = t;
   }
   ev_ = evs_[0];
+  overlap_now_ = false;                     // (the cap on the search's blocks belongs to this call's schedule, not to the entries that follow)
+  if (!expand_end()) classify_device(orig_b1, d_o1, orig_b2, d_o2, n, total1, total2, results, matches, match_cap, match_extent, src, compact);
 }
 
 void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,

@@ -115,6 +115,10 @@ struct DevView {            // passed by value to kernels
   uint64_t secondary_hit_len;
   double secondary_factor;
   uint8_t rank_num[32];
+  // --expand-taxid: the pool the tail appends its lists to (exp_append in cfr_kernels.hip.inc); nullptr = not wanted
+  uint64_t *exp_pool;
+  unsigned long long *exp_cursor;
+  uint64_t exp_cap;
 };
 
 struct TailEntry { uint64_t seq_id, score; int32_t hit_length, k; };
@@ -173,6 +177,8 @@ class DeviceIndex {
   void run_batch_host(const uint8_t *bases1, const uint64_t *offs1, const uint8_t *bases2, const uint64_t *offs2,
                       size_t n, bool want_rows, BatchOut &out);
 
+  // --expand-taxid: the records the last classify call appended (slot, count, ids ...), on the host; empty without output_expanded
+  std::vector<uint64_t> expanded_raw_;
   cfr_batch_stats last_stats{};
   // reads of the last compact call whose values did not fit the narrow layout, in the wide one (cfr_compact_wide_reads)
   static constexpr size_t kWideSideCap = 65536;
@@ -218,6 +224,9 @@ class DeviceIndex {
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
   void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true);
+  void expand_begin();                   // before the kernels of a classify call: pool in place, cursor zero, both views know it
+  bool expand_end();                     // behind them: false = the pool was too small (it has been enlarged: run the call again)
+  uint64_t exp_cap_ = 0;
   bool one_launch_ready() const { return fused_tail_ && fused_post_ && locate_direct() && !view_.prot.enabled; }
 
   const HostIndex *host_;

@@ -45,7 +45,7 @@ void lineage(const Taxonomy &t, uint64_t x, std::vector<uint64_t> &path) {
 
 }  // namespace
 
-// Taxonomy::LCA (Taxonomy.hpp:733-836), without the child bookkeeping
+// Taxonomy::LCA (Taxonomy.hpp:733-836); the child bookkeeping is tax_lca_children below
 uint64_t tax_lca(const Taxonomy &t, const std::vector<uint64_t> &ids) {
   const int cnt = (int)ids.size();
   int k = 0;
@@ -70,13 +70,43 @@ uint64_t tax_lca(const Taxonomy &t, const std::vector<uint64_t> &ids) {
   return t.root;
 }
 
-// Taxonomy::ReduceTaxIds (Taxonomy.hpp:839-973), without the child bookkeeping
-void tax_reduce(const Taxonomy &t, const std::vector<uint64_t> &ids, int k, std::vector<uint64_t> &out) {
+// lcaChildTaxIds of Taxonomy::LCA (Taxonomy.hpp:771-777, 806-813, 822-830) for its result `lca`: the reference keeps one ordered set per
+// node of the first id's lineage - the lineage's own node below it, and for every other id the node at which its path leaves the
+// lineage - and hands back the set of the LCA's place.  An id whose path leaves further down shares the lineage's node below the
+// LCA, the LCA itself and root ids leave nothing: so the set is { child of lca on the way down to x : x in ids, x not a root, x != lca }.
+void tax_lca_children(const Taxonomy &t, const std::vector<uint64_t> &ids, uint64_t lca, std::vector<uint64_t> &children) {
+  children.clear();
+  for (uint64_t x : ids) {
+    if (x == t.parent[x] || x == lca) continue;
+    for (;;) {
+      const uint64_t p = t.parent[x];
+      if (p == lca || p == t.parent[p]) break;
+      x = p;
+    }
+    children.push_back(x);
+  }
+  std::sort(children.begin(), children.end());              // std::map order
+  children.erase(std::unique(children.begin(), children.end()), children.end());
+}
+
+// Taxonomy::ReduceTaxIds (Taxonomy.hpp:839-973).  children (promotedChildTaxIds) may be null; otherwise it comes back with one list
+// per entry of `out` - or with none, where the reference pushes none (Classifier.hpp:823 prints empty strings then).
+void tax_reduce(const Taxonomy &t, const std::vector<uint64_t> &ids, int k, std::vector<uint64_t> &out,
+                std::vector<std::vector<uint64_t>> *children) {
   out.clear();
+  if (children) children->clear();
   if ((int)ids.size() <= k) { out = ids; return; }
   for (uint64_t x : ids)
-    if (x >= t.node_cnt) { out.push_back(t.node_cnt); return; }
-  if (k == 1) { out.push_back(tax_lca(t, ids)); return; }
+    if (x >= t.node_cnt) {
+      out.push_back(t.node_cnt);
+      if (children) children->push_back(ids);              // :866-872: every input id, as it came
+      return;
+    }
+  if (k == 1) {
+    out.push_back(tax_lca(t, ids));
+    if (children) { children->emplace_back(); tax_lca_children(t, ids, out[0], children->back()); }
+    return;
+  }
   const uint8_t unknown_level = t.rank_num[0];
   std::vector<std::vector<uint64_t>> level(32);      // sorted-unique id sets per rank level
   auto insert = [](std::vector<uint64_t> &s, uint64_t x) {
@@ -103,10 +133,28 @@ void tax_reduce(const Taxonomy &t, const std::vector<uint64_t> &ids, int k, std:
   for (; r < unknown_level; ++r) if ((int)level[r].size() <= k) break;
   out = level[r];
   if (out.empty()) out.push_back(t.root);
+  else if (children && r > 0) {
+    // :939-971: a member of the set one level down belongs to the first node above it that is filed at exactly this level - if a
+    // higher-ranked (or unranked: the largest number) node comes first, to nobody
+    children->assign(out.size(), {});
+    for (uint64_t member : level[r - 1]) {
+      uint64_t x = member;
+      while (x != t.parent[x]) {
+        x = t.parent[x];
+        const uint8_t lv = t.rank_num[t.rank[x]];
+        if (lv > r) break;
+        if (lv == r) {
+          auto it = std::lower_bound(out.begin(), out.end(), x);
+          if (it != out.end() && *it == x) (*children)[(size_t)(it - out.begin())].push_back(member);
+          break;
+        }
+      }
+    }
+  }
 }
 
 void classify_read(const HostIndex &h, const cfr_hit *hits, size_t nhits, const uint64_t *row_begin, const uint64_t *row_vals,
-                   int32_t query_len, cfr_result &res, std::vector<cfr_match> &matches) {
+                   int32_t query_len, cfr_result &res, std::vector<cfr_match> &matches, ExpandedLists *expanded) {
   const cfr_params &P = h.params;
   RecordMap rec[2];
   SeqRecord prev_uniq{0, 0, 0};
@@ -174,23 +222,34 @@ void classify_read(const HostIndex &h, const cfr_hit *hits, size_t nhits, const 
     std::vector<uint64_t> tids, promoted;
     tids.reserve(best_ids.size());
     for (uint64_t id : best_ids) tids.push_back(seq_to_tax(h.tax, id));
-    tax_reduce(h.tax, tids, P.max_result, promoted);
+    std::vector<std::vector<uint64_t>> children;
+    tax_reduce(h.tax, tids, P.max_result, promoted, expanded ? &children : nullptr);
     for (uint64_t ctid : promoted) matches.push_back(cfr_match{ctid, orig_taxid(h.tax, ctid), 1, 0});
+    if (expanded && children.size() == promoted.size()) {      // Classifier.hpp:821-839
+      expanded->spans.resize(matches.size(), cfr_span{0, 0});
+      for (size_t q = 0; q < promoted.size(); ++q) {
+        expanded->spans[res.match_begin + q] = cfr_span{expanded->ids.size(), children[q].size()};
+        for (uint64_t c : children[q]) expanded->ids.push_back(orig_taxid(h.tax, c));
+      }
+    }
   }
+  if (expanded) expanded->spans.resize(matches.size(), cfr_span{0, 0});
   res.n_match = (int32_t)(matches.size() - res.match_begin);
   res.pad = 0;
 }
 
 void classify_batch_tail(const HostIndex &h, const DeviceIndex::BatchOut &b, size_t n, int threads, cfr_result *results,
-                         std::vector<cfr_match> &matches) {
+                         std::vector<cfr_match> &matches, ExpandedLists *expanded) {
   if (threads < 1) threads = 1;
   if ((size_t)threads > n) threads = n ? (int)n : 1;
   std::vector<std::vector<cfr_match>> part((size_t)threads);
+  std::vector<ExpandedLists> xpart(expanded ? (size_t)threads : 0);
   auto work = [&](int tid) {
     const size_t lo = n * (size_t)tid / (size_t)threads, hi = n * (size_t)(tid + 1) / (size_t)threads;
     for (size_t i = lo; i < hi; ++i) {
       const uint64_t hb = b.hit_begin[i], he = b.hit_begin[i + 1];
-      classify_read(h, b.hits.data() + hb, he - hb, b.row_begin.data() + hb, b.row_vals.data(), b.read_len[i], results[i], part[tid]);
+      classify_read(h, b.hits.data() + hb, he - hb, b.row_begin.data() + hb, b.row_vals.data(), b.read_len[i], results[i], part[tid],
+                    expanded ? &xpart[tid] : nullptr);
     }
   };
   if (threads == 1) work(0);
@@ -201,11 +260,17 @@ void classify_batch_tail(const HostIndex &h, const DeviceIndex::BatchOut &b, siz
   }
   // stitch per-thread match arrays; reads were assigned in contiguous blocks so order is preserved
   matches.clear();
+  if (expanded) { expanded->spans.clear(); expanded->ids.clear(); }
   for (int t = 0; t < threads; ++t) {
     const size_t lo = n * (size_t)t / (size_t)threads, hi = n * (size_t)(t + 1) / (size_t)threads;
     const uint64_t shift = matches.size();
     for (size_t i = lo; i < hi; ++i) results[i].match_begin += shift;
     matches.insert(matches.end(), part[t].begin(), part[t].end());
+    if (expanded) {
+      const uint64_t idshift = expanded->ids.size();
+      for (cfr_span s : xpart[t].spans) { s.begin += idshift; expanded->spans.push_back(s); }
+      expanded->ids.insert(expanded->ids.end(), xpart[t].ids.begin(), xpart[t].ids.end());
+    }
   }
 }
 

@@ -59,7 +59,8 @@ typedef struct {
   int32_t max_result;               /* -k, default 1 */
   int32_t min_hit_len;              /* --min-hitlen, <=0: infer (Classifier.hpp:113-129) */
   int32_t max_result_per_hit_factor;/* --hitk-factor, default 40 */
-  int32_t reserved;
+  int32_t output_expanded;          /* --expand-taxid (outputExpandedResult, Classifier.hpp:22): keep, for every reported tax id, the ids that
+                                       ReduceTaxIds / LCA promoted into it; they are handed out by cfr_classify_batch_expanded */
   uint64_t consider_secondary_hit_len;     /* 2000 */
   double consider_secondary_score_factor;  /* 0.995 */
 } cfr_params;
@@ -195,6 +196,19 @@ cfr_status cfr_classify_batch_packed(cfr_dev_index *d, const uint64_t *packed1, 
                                      const uint64_t *packed2, const uint64_t *offsets2, size_t n,
                                      cfr_result *results, cfr_match *matches, size_t match_cap, size_t *n_matches);
 
+/* cfr_classify_batch with the lists of `--expand-taxid` (Classifier.hpp:792-838; Taxonomy::ReduceTaxIds / LCA with
+ * promotedChildTaxIds, Taxonomy.hpp:733-973): for every match slot m of `matches` the ORIGINAL tax ids (GetOrigTaxId) of the
+ * children that were promoted into matches[m] are ids[spans[m].begin .. spans[m].begin + spans[m].count), in the order the
+ * reference prints them; count 0 = the empty string (every sequence-level match, Classifier.hpp:792-795).  The index must have
+ * been opened with cfr_params.output_expanded = 1 (CFR_ERR_ARG otherwise).  spans: match_cap entries, every one is written.
+ * *n_ids = ids used; CFR_ERR_CAPACITY (and *n_ids = the number needed) when ids_cap is too small.  SDUST on the device and the
+ * streamed upload work as in cfr_classify_batch. */
+typedef struct { uint64_t begin, count; } cfr_span;
+cfr_status cfr_classify_batch_expanded(cfr_dev_index *d, const uint8_t *bases1, const uint64_t *offsets1,
+                                       const uint8_t *bases2, const uint64_t *offsets2, size_t n,
+                                       cfr_result *results, cfr_match *matches, cfr_span *spans, size_t match_cap, size_t *n_matches,
+                                       uint64_t *ids, size_t ids_cap, size_t *n_ids);
+
 /* Asynchronous form of cfr_classify_batch.  The reference overlaps reading, classification and output of consecutive batches
  * (CentrifugerClass.cpp:776-800: the next batch is read while the threads classify this one); a caller of this library gets the
  * same by submitting batch k+1 before it waits for batch k:
@@ -263,6 +277,12 @@ cfr_status cfr_classify_from_hits(const cfr_index *idx, const cfr_hit *hits, con
                                   size_t n, int threads, cfr_result *results, cfr_match *matches, size_t match_cap,
                                   size_t *n_matches);
 
+/* cfr_classify_from_hits with the lists of --expand-taxid (see cfr_classify_batch_expanded; idx opened with output_expanded = 1) */
+cfr_status cfr_classify_from_hits_expanded(const cfr_index *idx, const cfr_hit *hits, const uint64_t *hit_begin,
+                                           const uint64_t *row_begin, const uint64_t *row_vals, const int32_t *query_len,
+                                           size_t n, int threads, cfr_result *results, cfr_match *matches, cfr_span *spans, size_t match_cap,
+                                           size_t *n_matches, uint64_t *ids, size_t ids_cap, size_t *n_ids);
+
 /* ---- host helpers around the path ---- */
 /* SDUST pre-step (Dustmasker.hpp:357-421 + CentrifugerClass.cpp:283-289): masked bases -> 'N', in place */
 cfr_status cfr_dust_mask_batch(uint8_t *bases, const uint64_t *offsets, size_t n, int threads);
@@ -281,6 +301,11 @@ cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t
 size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches,
                       char *buf, size_t cap);
 const char *cfr_tsv_header(void);
+/* the same rows with the expandedTaxIDs column of --expand-taxid (ResultWriter.hpp:194-195, 226-227, 239-240): spans / ids as
+ * cfr_classify_batch_expanded filled them */
+size_t cfr_format_tsv_expanded(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches,
+                               const cfr_span *spans, const uint64_t *ids, char *buf, size_t cap);
+const char *cfr_tsv_header_expanded(void);
 
 /* ---- index writer (outside the classification path) ----
  * What `centrifuger-build` produces (Builder::Build + FMBuilder, Builder.hpp:86-313, compactds/FMBuilder.hpp:209-313):
