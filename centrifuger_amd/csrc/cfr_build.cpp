@@ -391,17 +391,28 @@ void build_protein_index_files(const BuildInput &in, const BuildOptions &opt, co
   const uint64_t nsamp = (n + rate - 1) / rate, nk = 1ull << (kProtBits * w);
   std::vector<uint64_t> sampled(nsamp), ftab(2 * nk, 0), end_sa(end_markers);
   {
-    // row ranges in parallel; a range keeps its own (first row, count) table for the keys it meets and the tables are merged in
-    // range order, so "first" is the smallest row of a key exactly as in the reference's single pass
+    // Row ranges in parallel, ONE table (the reference allocates it once too: 2 x 32^w entries are 16 GiB at w = 6).  The rows of a key
+    // - the suffixes that begin with its w symbols - stand together in the suffix array, so a key whose rows lie inside a thread's range
+    // is that thread's alone and goes straight into the table; only the run a range begins in and the one it ends in can be shared with
+    // a neighbour, and those two (key, first row, count) triples per thread are added afterwards in range order - "first" is then the
+    // smallest row of a key exactly as in the reference's single pass.  (Suffixes shorter than w have no key and break no run.)
     int threads = opt.threads > 0 ? (int)std::min<uint64_t>((uint64_t)opt.threads, n)
                                   : (int)std::min<uint64_t>(std::min(32u, std::max(1u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, n >> 20));
-    std::vector<std::vector<uint64_t>> part((size_t)threads);
+    struct Run { uint64_t key = ~0ull, first = 0, count = 0; };
+    std::vector<Run> head((size_t)threads), tail((size_t)threads);
     std::vector<uint64_t> fi((size_t)threads, ~0ull);
     std::vector<std::thread> th;
     for (int t = 0; t < threads; ++t) th.emplace_back([&, t]() {
-      std::vector<uint64_t> &ft = part[(size_t)t];
-      ft.assign(2 * nk, 0);
       const uint64_t lo = n * (uint64_t)t / (uint64_t)threads, hi = n * (uint64_t)(t + 1) / (uint64_t)threads;
+      Run cur;
+      bool first_run = true;
+      auto flush = [&](bool last) {
+        if (cur.key == ~0ull) return;
+        if (first_run) head[(size_t)t] = cur;
+        else if (last) tail[(size_t)t] = cur;
+        else { ftab[2 * cur.key] = cur.first; ftab[2 * cur.key + 1] = cur.count; }
+        first_run = false;
+      };
       for (uint64_t i = lo; i < hi; ++i) {
         const uint64_t p = sa[i];
         if (p == 0) { fi[(size_t)t] = i; B[i] = T[n - 1]; } else B[i] = T[p - 1];
@@ -409,19 +420,19 @@ void build_protein_index_files(const BuildInput &in, const BuildOptions &opt, co
         if (p + w <= n) {                                                       // FMBuilder.hpp:256-283: T.PackRead(p, w) - the first symbol in the low bits
           uint64_t key = 0;
           for (uint32_t k = 0; k < w; ++k) key |= (uint64_t)T[p + k] << (kProtBits * k);
-          if (ft[2 * key + 1] == 0) ft[2 * key] = i;
-          ++ft[2 * key + 1];
+          if (key != cur.key) { flush(false); cur.key = key; cur.first = i; cur.count = 0; }
+          ++cur.count;
         }
         if (i < end_markers) end_sa[i] = seq_of(p + 1);                         // rows of the '$' suffixes come first (FMBuilder.hpp:306-311)
       }
+      flush(true);
     });
     for (auto &x : th) x.join();
     for (int t = 0; t < threads; ++t) {
       if (fi[(size_t)t] != ~0ull) first_isa = fi[(size_t)t];
-      const std::vector<uint64_t> &ft = part[(size_t)t];
-      for (uint64_t k = 0; k < nk; ++k) if (ft[2 * k + 1]) {
-        if (ftab[2 * k + 1] == 0) ftab[2 * k] = ft[2 * k];
-        ftab[2 * k + 1] += ft[2 * k + 1];
+      for (const Run *r : {&head[(size_t)t], &tail[(size_t)t]}) if (r->key != ~0ull) {
+        if (ftab[2 * r->key + 1] == 0) ftab[2 * r->key] = r->first;
+        ftab[2 * r->key + 1] += r->count;
       }
     }
   }
@@ -515,7 +526,14 @@ void build_protein_index_files(const BuildInput &in, const BuildOptions &opt, co
 }  // namespace
 
 void build_index_files(const BuildInput &in, const BuildOptions &opt, const std::string &prefix, BuildReport *rep) {
-  if (opt.protein) { build_protein_index_files(in, opt, prefix, rep); return; }
+  if (opt.protein) {
+    // the reference's rule (CentrifugerBuild.cpp:221-227): a protein index built with the nucleotide default of 10 initial-lookup
+    // characters gets 4 - for every caller of the library, not only for the command line
+    BuildOptions po = opt;
+    if (po.ftab_chars == 10) po.ftab_chars = 4;
+    build_protein_index_files(in, po, prefix, rep);
+    return;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   auto say = [&](const std::string &m) { if (opt.verbose) fprintf(stderr, "[cfr-build] %s\n", m.c_str()); };

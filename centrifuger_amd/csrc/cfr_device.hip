@@ -946,8 +946,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
   static const int sm_minb = dbg_env("CFR_PROT_SM_MINB") ? atoi(dbg_env("CFR_PROT_SM_MINB")) : 1;
   static const int minb = dbg_env("CFR_PROT_MINB") ? atoi(dbg_env("CFR_PROT_MINB")) : 1;    // k_search_prot's register budget: 8 blocks per CU = 64 VGPRs (a few spills), 6 = 80
   if (sm) {
-    static int occ1 = 0, occ2 = 0;
-    int &occ = paired ? occ2 : occ1;
+    int &occ = paired ? prot_occ_[1] : prot_occ_[0];        // (per image: two images on two devices may be inside this at once)
     if (occ == 0) {
       hipError_t e = paired ? (sm_minb == 6 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<2, 6>, kBlock, 0)
                                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_prot_sm<2, 1>, kBlock, 0))
@@ -1375,6 +1374,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   const bool one_launch = fused && stride > 0 && fused_post_ && !view_.prot.enabled;   // k_adjust_tail: no host round trip in a piece
   // streamed host inputs (classify_host): bases of piece k are copied on the h2d stream and packed right before its search
   std::vector<uint8_t> have_piece(nsub, by_piece ? 0 : 1);
+  uint64_t sent_end1 = 0, sent_end2 = 0;       // packed host blocks: the first block of each mate's buffer that has not been copied up yet
   auto bring_piece = [&](size_t k) {
     if (!by_piece || have_piece[k]) return;
     const size_t lo = pieces[k].first, hi = lo + pieces[k].second;
@@ -1387,21 +1387,24 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       have_piece[k] = 1;
       return;
     }
-    auto one = [&](const uint8_t *hb, const uint64_t *hp, const uint64_t *ho, const uint8_t *db, uint64_t *packed) {
+    auto one = [&](const uint8_t *hb, const uint64_t *hp, const uint64_t *ho, const uint8_t *db, uint64_t *packed, uint64_t &sent_end) {
       const uint64_t a = ho[lo], b = ho[hi];
       if (b <= a) return;
       if (hp) {
-        // packed blocks: into the search kernel's own buffer (a block shared with the neighbouring sub-batch arrives twice with the
-        // same bits) - or, with SDUST, into a staging copy (the search's blocks are then packed from the masked characters) - and
-        // unpacked, this sub-batch's characters only, for SDUST and the post stage
+        // packed blocks: into the search kernel's own buffer - or, with SDUST, into a staging copy (the search's blocks are then packed
+        // from the masked characters) - and unpacked, this sub-batch's characters only, for SDUST and the post stage.  The block a
+        // sub-batch shares with the one before it came with that one (same stream, in order) and is not written again: the search
+        // of the previous sub-batch may still be reading it.
         const uint64_t k0 = a >> 4, k1 = (b + 15) >> 4;
-        HIP_CHECK(hipMemcpyAsync(packed + k0, hp + k0, (k1 - k0) * 8, hipMemcpyHostToDevice, h2d_stream_));
+        const uint64_t kc = std::max(k0, std::min(sent_end, k1));
+        if (k1 > kc) HIP_CHECK(hipMemcpyAsync(packed + kc, hp + kc, (k1 - kc) * 8, hipMemcpyHostToDevice, h2d_stream_));
+        sent_end = k1;
         k_unpack_reads<<<grid_for(k1 - k0), kBlock, 0, h2d_stream_>>>(packed + k0, k1 - k0, const_cast<uint8_t *>(db) + (k0 << 4), a - (k0 << 4), b - (k0 << 4));
         HIP_CHECK(hipGetLastError());
       } else HIP_CHECK(hipMemcpyAsync(const_cast<uint8_t *>(db) + a, hb + a, b - a, hipMemcpyHostToDevice, h2d_stream_));
     };
-    one(src->b1, src->p1, src->o1, d_b1, src->stage1 ? src->stage1 : packed1_);
-    if (paired) one(src->b2, src->p2, src->o2, d_b2, src->stage2 ? src->stage2 : packed2_);
+    one(src->b1, src->p1, src->o1, d_b1, src->stage1 ? src->stage1 : packed1_, sent_end1);
+    if (paired) one(src->b2, src->p2, src->o2, d_b2, src->stage2 ? src->stage2 : packed2_, sent_end2);
     if (dust_ && !view_.prot.enabled) {
       // masked on a stream of its own, behind the piece's copy: the copy stream goes straight on with the next piece (the link
       // is what bounds this entry: 187 MB per piece at ~47 GB/s = 4 ms, the mask kernel 1.1-1.4 ms - on the copy stream
