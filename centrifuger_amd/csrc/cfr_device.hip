@@ -33,11 +33,12 @@ inline const char *dbg_env(const char *name) {
 }
 
 constexpr int kBlock = 256;
+constexpr size_t kCtlWords = 4;      // words of a sub-batch's control block the host reads back: pool overflow, reads folded by small / large teams, reads left to k_adjust_tail
 inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + block - 1) / block); }
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_SLOW, S_SLOW1, S_COUNT
 };
 
 }  // namespace
@@ -104,7 +105,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     // lands on the search stream's queue runs behind it instead of beside it (seen with the third image of a process)
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
-    if (least != greatest) HIP_CHECK(hipStreamCreateWithPriority(&tail_stream_, hipStreamNonBlocking, least));
+    const bool high = dbg_env("CFR_TAIL_PRIO") && atoi(dbg_env("CFR_TAIL_PRIO")) > 0;      // A/B: the post stage in the HIGHEST class (profiles/r5_ab_post_fast.txt)
+    if (least != greatest) HIP_CHECK(hipStreamCreateWithPriority(&tail_stream_, hipStreamNonBlocking, high ? greatest : least));
     else HIP_CHECK(hipStreamCreateWithFlags(&tail_stream_, hipStreamNonBlocking));
   }
   for (auto &e : search_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -873,10 +875,20 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     // the search reads the buffers through their packed form (k_pack_reads); callers of this function pack first
     // few chains per lane (long reads): chains are handed out dynamically (DYN), one atomic per chain
     bool dyn = nchains < 8ull * blocks * kBlock && (total1 + total2) / std::max<size_t>(1, nchains) >= 500;    // (per chain: half the mean read)
-    if (const char *e = dbg_env("CFR_SEARCH_DYN")) dyn = atoi(e) != 0;
+    // short reads by WAVE TILES (round 5: a wave draws 64 chains with one atomic and its lanes share them by ballot, k_search_chains_v2):
+    // pairs 24.6 -> 23.9 ms per 10 M pairs (the four chains of a pair are of very different lengths: the static hand-out ends with the
+    // lanes that drew the long ones), 20 strains 28.4 -> 27.6 ms, cfg2 unchanged (11.85 ms either way: it keeps the static hand-out);
+    // tiles of 512 chains LOSE (cfg2 search 9.5 -> 12.5 ms: the launch ends with the waves that still hold a tile).
+    // profiles/r5_ab_post_and_tiles.txt.  CFR_SEARCH_DYN=0 / 1 / 2: static / per-lane draws / wave tiles.
+    int dyn_mode = -1;
+    const bool short_reads = (total1 + total2) / std::max<size_t>(1, nchains) < 500;
+    if (!dyn && short_reads && nchains > 4ull * blocks * kBlock && nchains < 0xfff00000ull && (paired || heavy_frac_ > 0.2)) { dyn = true; dyn_mode = 2; }
+    if (const char *e = dbg_env("CFR_SEARCH_DYN")) { dyn_mode = atoi(e); dyn = dyn_mode != 0; }
     // short reads handed out dynamically (so that the post stage of the previous sub-batch can run beside this search: a block that
     // starts late then simply takes fewer chains): eight chains per draw; long reads: one
-    const uint32_t dyn_chunk = dyn && (total1 + total2) / std::max<size_t>(1, nchains) < 500 ? 8u : 1u;
+    // CFR_SEARCH_DYN=2 (round 5): wave tiles - a wave draws 512 chains (CFR_SEARCH_TILE) with one atomic and hands them to its lanes by ballot
+    uint32_t dyn_chunk = dyn && (total1 + total2) / std::max<size_t>(1, nchains) < 500 ? 8u : 1u;
+    if (dyn && dyn_mode == 2 && nchains < 0xfff00000ull) dyn_chunk = dbg_env("CFR_SEARCH_TILE") ? (uint32_t)std::max(64, atoi(dbg_env("CFR_SEARCH_TILE"))) : 64u;
     unsigned long long *d_ctr = nullptr;
     if (dyn) {
       d_ctr = (unsigned long long *)scratch(S_P5, 16 * 8) + 15;
@@ -1333,8 +1345,8 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     } else {
       // one launch that stores the pieces' boundaries (and their hit-list offsets) into pinned host memory, one synchronisation
       static_assert(kMaxSub + 1 <= 17, "PieceFirsts");
-      unsigned long long *pin = (unsigned long long *)pinned((2 + 3 * kMaxSub + 3 * (kMaxSub + 1)) * 8);
-      uint64_t *pb1 = (uint64_t *)(pin + 2 + 3 * kMaxSub), *pb2 = pb1 + (kMaxSub + 1), *ph = pb2 + (kMaxSub + 1);
+      unsigned long long *pin = (unsigned long long *)pinned((2 + kCtlWords * kMaxSub + 3 * (kMaxSub + 1)) * 8);
+      uint64_t *pb1 = (uint64_t *)(pin + 2 + kCtlWords * kMaxSub), *pb2 = pb1 + (kMaxSub + 1), *ph = pb2 + (kMaxSub + 1);
       PieceFirsts pf;
       pf.n = (uint32_t)(nsub + 1);
       for (size_t k = 0; k <= nsub; ++k) pf.at[k] = k < nsub ? pieces[k].first : n;
@@ -1474,7 +1486,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(results) + lo * res_bytes, d_res, cnt * res_bytes, hipMemcpyDeviceToHost, copy_stream_));
       if (extent) HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char *>(matches) + stride * lo * match_bytes, d_match, extent * match_bytes, hipMemcpyDeviceToHost, copy_stream_));
     }
-    if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, 24, hipMemcpyDeviceToHost, copy_stream_));     // overflow flag + the two team counts
+    if (d_flag) HIP_CHECK(hipMemcpyAsync(h_flag, d_flag, kCtlWords * 8, hipMemcpyDeviceToHost, copy_stream_));     // overflow flag, the two team counts, the reads k_post_fast left to k_adjust_tail
     HIP_CHECK(hipEventRecord(copy_done_[par], copy_stream_));
   };
   auto out_buffers = [&](size_t k, uint64_t extent, cfr_result *&d_res, cfr_match *&d_match, hipStream_t st) {
@@ -1488,11 +1500,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   std::vector<size_t> todo;                 // pieces still to do
   for (size_t k = 0; k < nsub; ++k) todo.push_back(k);
   if (one_launch) {
-    unsigned long long *pin = (unsigned long long *)pinned((2 + 3 * kMaxSub + 3 * (kMaxSub + 1)) * 8);    // one block: the pointers below stay valid
+    unsigned long long *pin = (unsigned long long *)pinned((2 + kCtlWords * kMaxSub + 3 * (kMaxSub + 1)) * 8);    // one block: the pointers below stay valid
     // per sub-batch three words, fetched with ONE copy behind its post stage: pool-overflow flag, reads the small teams of
     // k_tail_heavy folded, reads the large teams folded (= ctl[1..3] of the sub-batch's control block)
     unsigned long long *pctl = pin + 2;
-    for (size_t k = 0; k < 3 * kMaxSub; ++k) pctl[k] = 0;
+    for (size_t k = 0; k < kCtlWords * kMaxSub; ++k) pctl[k] = 0;
     if (!pool_cap_) pool_cap_ = std::max<uint64_t>(8ull * sb, 1ull << 20);
     const uint64_t pool_limit = std::max<uint64_t>(256ull * sb, 1ull << 26);      // ~10 GB at the default sub-batch
     for (int attempt = 0; attempt < 4 && !todo.empty(); ++attempt) {
@@ -1500,7 +1512,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       uint64_t *pool_v = (uint64_t *)scratch(S_POOL_V, pool_cap_ * 8);
       for (size_t k : todo) {
         const size_t lo = pieces[k].first, cnt = pieces[k].second;
-        pctl[3 * k] = 0;
+        pctl[kCtlWords * k] = 0;
         ev_ = evs_[k];
         if (attempt == 0) { bring_piece(k); pack_piece(k); }
         // the post stage runs on its own stream: it is a chain of dependent gathers per read (4 fabric requests per read,
@@ -1519,11 +1531,11 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
           HIP_CHECK(hipEventRecord(search_done_[par], stream_));
           HIP_CHECK(hipStreamWaitEvent(ts, search_done_[par], 0));
         }
-        unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 32);    // pool cursor, overflow flag, heavy reads
+        unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 64);    // pool cursor, overflow flag, heavy reads (two tiers), slow reads
         cfr_result *d_res;
         cfr_match *d_match;
         out_buffers(k, stride * cnt, d_res, d_match, ts);               // (also orders the memset below behind the copy of ctl)
-        HIP_CHECK(hipMemsetAsync(ctl, 0, 32, ts));
+        HIP_CHECK(hipMemsetAsync(ctl, 0, 64, ts));
         // reads whose fold does not fit the registers (many located rows) are listed and folded by teams of lanes afterwards
         uint64_t *heavy = team_tail_ ? (uint64_t *)scratch(par ? S_HEAVY1 : S_HEAVY, std::max(sb, cnt) * 32) : nullptr;
         // reads with more located rows than this go straight to the large teams (distinct ids <= rows: 48 fit the small teams' table; up to
@@ -1535,12 +1547,41 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         const unsigned tail_grid = tail_overlap && tail_blocks_per_cu_ ? std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * tail_blocks_per_cu_)) : grid_for(cnt);
         // pairs: the image description behind a pointer (k_adjust_tail_p: no 1 KB copy into every lane's scratch); CFR_TAIL_VIEW_PTR=0: by value
         static const bool view_ptr = !(dbg_env("CFR_TAIL_VIEW_PTR") && atoi(dbg_env("CFR_TAIL_VIEW_PTR")) == 0);
-        if (paired && view_ptr && d_view_) k_adjust_tail_p<4><<<tail_grid, kBlock, 0, ts>>>(d_view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
-        else if (paired) k_adjust_tail<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
-        else k_adjust_tail<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
-                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows);
+        // CFR_POST_FAST=1 (round 5): the common read's post stage by k_post_fast - registers only, 94 of them, no scratch, so
+        // that its waves fit beside four waves of the search - which lists the reads that need more: team folds, or the full lane program of
+        // k_adjust_tail, which then runs over that list.  Built, parity-green (tests/test_gpu_variants.py) and NOT the default, because
+        // it measures slower where it was meant to help: cfg2 12.1 against 11.85 ms per step, pairs 24.4 against 23.9 (20 strains 27.1
+        // against 27.6).  What the measurements of profiles/r5_ab_post_and_tiles.txt say about the premise: with NO post stage at all the
+        // searches of a step take 9.4 ms against 9.5 (the "8.7 ms alone" is one 2 M-read launch, not ten launches of a step), so the post
+        // stage costs the search 0.15 ms, not 0.9; a post stage that co-resides MORE slows the search more (pairs: search 16.9 -> 19.9 ms
+        // with the lean kernel beside it, 18.6 -> 24.9 with the post stage in the highest stream priority) - the 128-register kernel that
+        // only gets the slots the search leaves is the better neighbour; and the ~70 reads per sub-batch whose boundary adjustment walks
+        // the index character by character take ~0.1 ms whatever their number, which one kernel hides among 1.25 M other reads and a
+        // second launch does not.
+        static const bool post_fast = dbg_env("CFR_POST_FAST") && atoi(dbg_env("CFR_POST_FAST")) != 0;
+        uint32_t *slow = nullptr;
+        unsigned long long *slow_cnt = nullptr;
+        unsigned fat_grid = tail_grid;
+        static const bool skip_post = dbg_env("CFR_SKIP_POST") && atoi(dbg_env("CFR_SKIP_POST")) != 0;   // diagnosis only: NO post stage (results are not computed) - what the searches cost with nothing beside them
+        if (skip_post) { copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &pctl[kCtlWords * k], ts); if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1); continue; }
+        // (the last sub-batch has no search beside it and nothing behind it to hide the second launch - a handful of reads whose boundary
+        // adjustment walks the index character by character, ~0.1 ms whatever their number: there the one kernel takes all reads)
+        static const int post_fast_last = dbg_env("CFR_POST_FAST_LAST") ? atoi(dbg_env("CFR_POST_FAST_LAST")) : 0;
+        if (post_fast && (k + 1 < nsub || post_fast_last || !tail_overlap)) {
+          slow = (uint32_t *)scratch(par ? S_SLOW1 : S_SLOW, std::max(sb, cnt) * 4);
+          slow_cnt = ctl + 4;
+          if (paired) k_post_fast<4><<<tail_grid, kBlock, 0, ts>>>(view_, d_o1 + lo, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt, d_res, d_match, stride, stride * lo,
+                                                               heavy, ctl + 2, heavy2, ctl + 3, direct_rows, slow, slow_cnt);
+          else k_post_fast<2><<<tail_grid, kBlock, 0, ts>>>(view_, d_o1 + lo, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt, d_res, d_match, stride, stride * lo,
+                                                          heavy, ctl + 2, heavy2, ctl + 3, direct_rows, slow, slow_cnt);
+          fat_grid = std::min<unsigned>(grid_for(cnt), (unsigned)(num_cus_ * 2));          // (its list is short - or everything, with hits on both strands throughout)
+        }
+        if (paired && view_ptr && d_view_) k_adjust_tail_p<4><<<fat_grid, kBlock, 0, ts>>>(d_view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows, slow, slow_cnt);
+        else if (paired) k_adjust_tail<4><<<fat_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, d_b2, d_o2 + lo, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                                      pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows, slow, slow_cnt);
+        else k_adjust_tail<2><<<fat_grid, kBlock, 0, ts>>>(view_, d_b1, d_o1 + lo, nullptr, nullptr, cnt, sbuf.hit_off, sbuf.raw, sbuf.chain_cnt,
+                                                               pool_e, pool_v, ctl, pool_cap_, (uint32_t *)(ctl + 1), d_res, d_match, stride, stride * lo, heavy, ctl + 2, heavy2, ctl + 3, direct_rows, slow, slow_cnt);
         if (heavy) {
           // two tiers: teams of 8 lanes with 48 table entries, then - for the reads whose ids do not fit (hundreds of strains per
           // species) - teams of 32 lanes with 192; what is left after that takes the single-lane form with pool scratch
@@ -1560,7 +1601,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
           }
         }
         HIP_CHECK(hipGetLastError());
-        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &pctl[3 * k], ts);
+        copy_out(k, d_res, d_match, stride * cnt, ctl + 1, &pctl[kCtlWords * k], ts);
         if (attempt == 0) last_stats.n_chains += cnt * (size_t)(paired ? 4 : 2);
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
@@ -1569,12 +1610,18 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
       if (attempt == 0) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }
       if (attempt == 0) {                    // what the next call's schedule goes by: the share of reads with a team fold
-        unsigned long long hv = 0;
-        for (size_t k = 0; k < nsub; ++k) hv += pctl[3 * k + 1] + pctl[3 * k + 2];     // (a read the small teams handed on counts twice: it is a threshold)
+        unsigned long long hv = 0, slow_reads = 0;
+        for (size_t k = 0; k < nsub; ++k) { hv += pctl[kCtlWords * k + 1] + pctl[kCtlWords * k + 2]; slow_reads += pctl[kCtlWords * k + 3]; }     // (a read the small teams handed on counts twice: it is a threshold)
         heavy_frac_ = (double)hv / (double)n;
+        last_slow_reads_ = slow_reads; last_team_reads_ = hv;
+        if (dbg_env("CFR_POST_STATS")) {                 // diagnostics: where the reads of this call went
+          unsigned long long t1 = 0, t2 = 0;
+          for (size_t k = 0; k < nsub; ++k) { t1 += pctl[kCtlWords * k + 1]; t2 += pctl[kCtlWords * k + 2]; }
+          fprintf(stderr, "[cfr] post stage of %zu reads: %llu left to k_adjust_tail, %llu folded by small teams, %llu by large teams\n", n, slow_reads, t1, t2);
+        }
       }
       std::vector<size_t> again;
-      for (size_t k : todo) if (pctl[3 * k]) again.push_back(k);              // the scratch pool ran dry in these
+      for (size_t k : todo) if (pctl[kCtlWords * k]) again.push_back(k);              // the scratch pool ran dry in these
       todo.swap(again);
       if (todo.empty() || pool_cap_ >= pool_limit || dbg_env("CFR_POOL_CAP")) break;
       pool_cap_ = std::min(pool_cap_ * 4, pool_limit);                   // kept for the calls that follow: the workload needs it

@@ -227,6 +227,9 @@ class DeviceIndex {
   void expand_begin();                   // before the kernels of a classify call: pool in place, cursor zero, both views know it
   bool expand_end();                     // behind them: false = the pool was too small (it has been enlarged: run the call again)
   uint64_t exp_cap_ = 0;
+ public:
+  uint64_t last_slow_reads_ = 0, last_team_reads_ = 0;   // of the last one-launch call: reads k_post_fast left to k_adjust_tail / to the team folds
+ private:
   int prot_occ_[2] = {0, 0};             // resident blocks per CU of k_search_prot_sm<1|2, ..> on this device (asked once per image)
   bool one_launch_ready() const { return fused_tail_ && fused_post_ && locate_direct() && !view_.prot.enabled; }
 

@@ -55,6 +55,15 @@ VARIANTS = {
     "run_block_layout_plain": {"CFR_LAYOUT": "rb", "CFR_FTABX_WIDTH": "0", "CFR_LOC_MEMO_GB": "0"},
     # hit-list offsets per sub-batch (k_caps + scan in front of every search) instead of one pass over the resident batch
     "hit_offsets_per_sub_batch": {"CFR_CAPS_ONCE": "0", "CFR_SUBBATCH": "43", "CFR_TAPER_FLOOR": "0"},
+    # round 5: the common read's post stage by k_post_fast (registers only), k_adjust_tail over the reads it lists
+    "post_fast": {"CFR_POST_FAST": "1"},
+    "post_fast_many_subbatches": {"CFR_POST_FAST": "1", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0", "CFR_POST_FAST_LAST": "1"},
+    "post_fast_on_the_search_stream": {"CFR_POST_FAST": "1", "CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "97"},
+    # chains handed out by wave tiles (the default for pairs) forced everywhere / off everywhere / per-lane draws of 8
+    "search_wave_tiles": {"CFR_SEARCH_DYN": "2"},
+    "search_wave_tiles_of_128_small_subbatches": {"CFR_SEARCH_DYN": "2", "CFR_SEARCH_TILE": "128", "CFR_SUBBATCH": "61"},
+    "search_static_hand_out": {"CFR_SEARCH_DYN": "0"},
+    "search_lane_draws": {"CFR_SEARCH_DYN": "1"},
 }
 
 
@@ -74,7 +83,9 @@ def test_parity_suite_under_switches(name):
                                         ("lean_image", {"CFR_FORCE_WIDE": "1", "CFR_FTABX_E8": "1", "CFR_LOC_MEMO_GB": "0"}),
                                         ("no_team_tail", {"CFR_TEAM_TAIL": "0"}), ("team_tail_k1", {"CFR_TEST_K": "1"}), ("team_tail_k5", {"CFR_TEST_K": "5"}),
                                         ("post_stage_overlapped", {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "20000"}),
-                                        ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"})])
+                                        ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"}),
+                                        ("post_fast", {"CFR_POST_FAST": "1", "CFR_SUBBATCH": "20000"}), ("post_fast_k5", {"CFR_POST_FAST": "1", "CFR_TEST_K": "5"}),
+                                        ("search_wave_tiles", {"CFR_SEARCH_DYN": "2", "CFR_SUBBATCH": "20000"}), ("search_static", {"CFR_SEARCH_DYN": "0"})])
 def test_many_strain_workload_under_switches(name, extra):
     """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
     tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""

@@ -41,6 +41,9 @@ BUDGET = {
     "k_dust<true>": (96, 0),
     "k_dust<false>": (96, 0),
     # the post stage
+    # the common read's post stage in <= 96 registers (5 waves per SIMD, or one beside four waves of the search)
+    "k_post_fast<2>": (96, 0),
+    "k_post_fast<4>": (96, 12),
     "k_adjust_tail<2>": (128, 24),
     "k_adjust_tail_p<4>": (128, 164),
     f"k_tail_heavy<2, {T1}>": (128, 68),
@@ -52,7 +55,7 @@ GROUPS = [
     [k for k in BUDGET if k.startswith("k_search_chains_v2<2")],
     [k for k in BUDGET if k.startswith("k_search_chains_v2<4")],
     [k for k in BUDGET if k.startswith(("k_search_prot_sm", "k_dust"))],
-    [k for k in BUDGET if k.startswith(("k_adjust_tail", "k_tail_heavy"))],
+    [k for k in BUDGET if k.startswith(("k_adjust_tail", "k_tail_heavy", "k_post_fast"))],
 ]
 
 
