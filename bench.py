@@ -375,6 +375,119 @@ def dust_roofline(pm, reads, dust_ms):
     return r
 
 
+def useful_bytes_per_read(pr, hits_per_read=0.0):
+    """bytes of the fetched lines the search kernel consumes, from its iteration mix (CFR_SEARCH_PROF): 16 B per K-mer entry / text window /
+    SA fetch / read-block pair, 24-48 B per BWT extend, 64 B per wide SA fetch, 32 B per hit written"""
+    return (16 * (pr.get("table", 0) + pr.get("table10", 0)) + 48 * pr.get("ext_two_records", 0) + 24 * (pr.get("ext", 0) - pr.get("ext_two_records", 0))
+            + 16 * pr.get("text_rows", 0) + 16 * pr.get("sa", 0) + 64 * pr.get("saw", 0) + 32 * pr.get("text_hits", 0) + 16 * pr.get("block_loads", 0) + 32 * hits_per_read)
+
+
+POST_KERNELS = ("k_adjust_tail", "k_post_fast", "k_tail_heavy")
+
+
+def live_pmc_post(args, cache, gpu=0):
+    """Counters of the POST-STAGE kernels (k_adjust_tail; k_tail_heavy's two tiers; k_post_fast when it is switched on), measured like
+    live_pmc: this script re-executed (--inner: one 2 M-read step = one launch of each) under rocprofv3 --pmc, one pass per counter group.
+    Returns {kernel: {counter: value, "ms": its duration in that pass}} or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof) or args.mode != "se":
+        return None
+    n_inner = min(2_000_000, args.reads)
+    inner = [sys.executable, os.path.abspath(__file__), "--inner", "--reads", str(n_inner), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--species", str(args.species), "--strains", str(args.strains), "--genome-len", str(args.genome_len), "--divergence-step", str(args.divergence_step),
+             "--read-len", str(args.read_len), "--seed", str(args.seed), "--builder", args.builder, "--cache", args.cache] + (["--index-gbp", str(args.index_gbp)] if args.index_gbp else [])
+    inner += ["--divergence-model", getattr(args, "divergence_model", "star")]
+    env = dict(os.environ, CFR_DEBUG_ENV="1", CFR_SUBBATCH=str(n_inner), CFR_TAPER_FLOOR="0", TMPDIR="/tmp")
+    for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k_, None)
+    if gpu:
+        env["HIP_VISIBLE_DEVICES"] = str(gpu)
+    groups = (["TCC_EA0_RDREQ_sum", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+              ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"])
+    out = {}
+    work = tempfile.mkdtemp(prefix="cfr_pmc_post_", dir="/tmp")
+    try:
+        for gi, group in enumerate(groups):
+            d = os.path.join(work, f"pass{gi}")
+            r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "|".join(POST_KERNELS),
+                                "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            if r.returncode != 0:
+                log("live PMC pass (post stage) failed:", r.stderr.decode()[-300:])
+                continue
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"].replace(" ", "")
+                    short = next((k_ for k_ in POST_KERNELS if k_ in name), None)
+                    if short is None:
+                        continue
+                    if short == "k_tail_heavy":
+                        short = "k_tail_heavy_large_teams" if ",32,256," in name else "k_tail_heavy_small_teams"
+                    e = out.setdefault(short, {})
+                    e[row["Counter_Name"]] = float(row["Counter_Value"])                 # last dispatch = the timed step
+                    e["ms"] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e6
+        return dict(out, reads=n_inner) if out else None
+    except Exception as e:
+        log("live PMC (post stage) unavailable:", repr(e))
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def post_stage_roofline(pm, reads, tail_ms, search_requests_per_read=None, hits_per_read=None, rows_per_read=None):
+    """The post stage (boundary adjustment, strand choice, locate, scoring, LCA) is a short chain of dependent gathers per read: what
+    bounds it is the latency of those gathers at the occupancy its registers allow, and what it costs the step is the requests it adds
+    to the fabric the search beside it is bound by.  So the object reports, per kernel and summed: time alone (the one-launch counter
+    pass), fabric requests and written bytes per read, L2 hit rate, VALU instructions per read and the share of the VALU issue rate."""
+    if not pm:
+        return None
+    n = pm["reads"]
+    kernels, tot_ms, tot_req, tot_wr, tot_valu = {}, 0.0, 0.0, 0.0, 0.0
+    for name, e in pm.items():
+        if not isinstance(e, dict):
+            continue
+        ms = e.get("ms", 0.0)
+        clock = (e["GRBM_GUI_ACTIVE"] / 8.0 / (ms / 1e3)) if e.get("GRBM_GUI_ACTIVE") and ms else 2.4e9
+        req = e.get("TCC_EA0_RDREQ_sum", 0.0)
+        kernels[name] = {
+            "ms_alone_per_step": ms / n * reads, "fabric_read_requests_per_read": req / n, "write_bytes_per_read": e.get("WRITE_SIZE", 0.0) * 1024 / n,
+            "l2_hit": (e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"])) if e.get("TCC_HIT_sum") is not None and (e.get("TCC_HIT_sum", 0) + e.get("TCC_MISS_sum", 0)) > 0 else None,
+            "valu_wave_instructions_per_read": (e["SQ_INSTS_VALU"] / n) if e.get("SQ_INSTS_VALU") is not None else None,
+            "valu_issue_frac": (e["SQ_INSTS_VALU"] / (ms / 1e3) / (1024.0 * clock / 2.0)) if e.get("SQ_INSTS_VALU") is not None and ms else None,
+            "waves_per_simd": (e["SQ_WAVE_CYCLES"] * 4.0 / ((ms / 1e3) * clock * 1024.0)) if e.get("SQ_WAVE_CYCLES") and ms else None,
+            "wait_fraction_of_wave_cycles": (e["SQ_WAIT_ANY"] / e["SQ_WAVE_CYCLES"]) if e.get("SQ_WAVE_CYCLES") and e.get("SQ_WAIT_ANY") is not None else None}
+        tot_ms += ms / n * reads
+        tot_req += req / n
+        tot_wr += e.get("WRITE_SIZE", 0.0) * 1024 / n
+        tot_valu += (e.get("SQ_INSTS_VALU") or 0.0) / n
+    traffic = (tot_req * BYTES_PER_RANDOM_REQUEST + tot_wr) * reads
+    out = {"bound": "hbm", "kernel": "+".join(sorted(kernels)), "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernels": kernels,
+           "ms_alone_per_step": tot_ms, "ms_inside_the_step_overlapped": tail_ms,
+           "fabric_read_requests_per_read": tot_req, "write_bytes_per_read": tot_wr, "valu_wave_instructions_per_read": tot_valu,
+           "traffic": traffic, "achieved_counter_traffic": traffic / (tot_ms / 1e3) / 1e9 if tot_ms else None,
+           "frac_counter_traffic": traffic / (tot_ms / 1e3) / 1e9 / HBM_PEAK_GBS if tot_ms else None,
+           "requests_per_s_alone": tot_req * reads / (tot_ms / 1e3) if tot_ms else None,
+           "gather_ceiling_frac_alone": tot_req * reads / (tot_ms / 1e3) / 48e9 if tot_ms else None,
+           "note": "one 2 M-read launch of each post-stage kernel under rocprofv3 --pmc (2 passes), scaled per read; ms_alone = the kernels with the chip to themselves, "
+                   "ms_inside_the_step = first start to last end beside the next sub-batch's search (mostly waiting for wave slots); frac = useful bytes "
+                   "(hits read, suffix-array entries, results written) over the time alone - a latency-bound stage: its cost to the step is the requests it adds"}
+    if search_requests_per_read:
+        out["share_of_the_step's_fabric_requests"] = tot_req / (tot_req + search_requests_per_read)
+    if hits_per_read is not None and rows_per_read is not None:
+        useful = 32.0 * hits_per_read + 4.0 * rows_per_read + 24.0 + 32.0       # hits, SA entries, the read's offsets / chain counts / hit offset, its result + match slot (compact layout)
+        out["useful_bytes_per_read"] = useful
+        out["achieved"] = useful * reads / (tot_ms / 1e3) / 1e9 if tot_ms else None
+        out["frac"] = out["achieved"] / HBM_PEAK_GBS if tot_ms else None
+        out["fetched_over_useful"] = (tot_req * BYTES_PER_RANDOM_REQUEST + tot_wr) / useful
+    else:
+        out["achieved"] = None
+        out["frac"] = None
+    return out
+
+
 def mini_roofline(pmc, reads, search_ms):
     """roofline object of a sub-result (same counter arithmetic as the main line's: 128-byte requests, WRITE_SIZE, 8 TB/s)"""
     if not pmc:
@@ -385,9 +498,16 @@ def mini_roofline(pmc, reads, search_ms):
     traffic = (per_read_rd + per_read_wr) * reads
     ach = traffic / (search_ms / 1e3) / 1e9
     req_s = pmc["rdreq"] / pmc["reads"] * reads / (search_ms / 1e3)
-    return {"bound": "hbm", "kernel": "k_search_chains_v2", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": search_ms, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+    useful = useful_bytes_per_read(pmc["prof"]) if pmc.get("prof") else None
+    ach_useful = (useful * reads / (search_ms / 1e3) / 1e9) if useful else None
+    return {"bound": "hbm", "kernel": "k_search_chains_v2", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel_ms": search_ms,
+            "achieved": ach_useful, "frac": (ach_useful / HBM_PEAK_GBS) if ach_useful else None, "frac_useful_bytes": (ach_useful / HBM_PEAK_GBS) if ach_useful else None,
+            "achieved_counter_traffic": ach, "frac_counter_traffic": ach / HBM_PEAK_GBS, "useful_bytes_per_read": useful,
+            "fetched_over_useful": ((per_read_rd + per_read_wr) / useful) if useful else None,
             "traffic": traffic, "fabric_read_requests_per_read": pmc["rdreq"] / pmc["reads"], "l2_hit": pmc.get("l2_hit"),
-            "gather_frac_of_48G_requests_per_s": req_s / 48e9, "iteration_mix_per_read": pmc.get("prof"), "traffic_source": pmc["source"]}
+            "gather": {"requests_per_s": req_s, "ceiling_per_s": 48e9, "frac": req_s / 48e9},
+            "gather_frac_of_48G_requests_per_s": req_s / 48e9, "iteration_mix_per_read": pmc.get("prof"), "traffic_source": pmc["source"],
+            "yardsticks": "frac = frac_useful_bytes (bytes of the fetched lines the kernel consumes / kernel time / 8 TB/s); frac_counter_traffic = fabric bytes by PMC / kernel time / 8 TB/s"}
 
 
 def live_pmc_protein(args, n):
@@ -501,6 +621,7 @@ def strains_config(torch, capi, ora, args, device, name="strains20"):
     if not args.no_pmc:
         a2.mode, a2.reads = "se", n
         out["roofline"] = mini_roofline(live_pmc(a2, cache, device.index or 0), n, st.search_ms)
+        out["post_stage"] = {"roofline": post_stage_roofline(live_pmc_post(a2, cache, device.index or 0), n, st.tail_ms, out["roofline"].get("fabric_read_requests_per_read"))}
     return out
 
 
@@ -706,7 +827,9 @@ def protein_mode(torch, capi, args, device):
             sp, tp = pm["k_search_prot"], pm.get("k_translate_prot", {})
             rd, wr = sp["TCC_EA0_RDREQ_sum"] * 128.0, sp["WRITE_SIZE"] * 1024.0
             out["roofline"] = {"bound": "hbm", "kernel": "k_search_prot", "peak": 8000.0, "unit": "GB/s", "kernel_ms": sp["ms"],
-                               "achieved": (rd + wr) / (sp["ms"] * 1e-3) / 1e9, "frac": (rd + wr) / (sp["ms"] * 1e-3) / 1e9 / 8000.0, "traffic": rd + wr,
+                               "achieved": None, "frac": None, "achieved_counter_traffic": (rd + wr) / (sp["ms"] * 1e-3) / 1e9,
+                               "frac_counter_traffic": (rd + wr) / (sp["ms"] * 1e-3) / 1e9 / 8000.0, "traffic": rd + wr,
+                               "yardsticks": "frac (useful bytes) is not instrumented for the translated search: frac_counter_traffic = fabric bytes by PMC / kernel time / 8 TB/s",
                                "fabric_read_requests_per_read": sp["TCC_EA0_RDREQ_sum"] / n, "read_bytes_per_read": rd / n, "write_bytes_per_read": wr / n,
                                "requests_per_s": sp["TCC_EA0_RDREQ_sum"] / (sp["ms"] * 1e-3),
                                "gather_ceiling_frac": sp["TCC_EA0_RDREQ_sum"] / (sp["ms"] * 1e-3) / 48e9,
@@ -804,7 +927,7 @@ def sub_config_40gbp(args, cfg):
                 "equals_oracle": (d.get("parity_oracle") or {}).get("equals_oracle"), "equals_oracle_on_first": (d.get("parity_oracle") or {}).get("reads"),
                 "parity_vs_reference_binary": {k_: (d.get("parity") or {}).get(k_) for k_ in ("reads", "timed_entry_tsv_identical_to_reference_no_dust", "tsv_identical_to_reference")} if d.get("parity") else None,
                 "cpu_baseline": {k_: (d.get("cpu_baseline") or {}).get(k_) for k_ in ("value", "unit", "cores", "kind", "sample")} if d.get("cpu_baseline") else None,
-                "roofline": {k_: roof.get(k_) for k_ in ("bound", "kernel", "peak", "unit", "achieved", "frac", "traffic", "kernel_ms", "fabric_read_requests_per_read", "l2_hit",
+                "roofline": {k_: roof.get(k_) for k_ in ("bound", "kernel", "peak", "unit", "achieved", "frac", "achieved_counter_traffic", "frac_counter_traffic", "fetched_over_useful", "traffic", "kernel_ms", "fabric_read_requests_per_read", "l2_hit",
                                                         "frac_useful_bytes", "x_reference_algorithm", "gather", "iteration_mix_per_read", "traffic_source")},
                 "index": d.get("index"), "multi_rank_load": d.get("multi_rank_load"), "seconds": wall,
                 "note": f"`bench.py --config {cfg}` in its own process on this GPU: BASELINE {'configs[3]' if cfg == 'cfg4' else 'configs[4]'} per rank (the 8-GPU job is 8 such ranks, index replicated)"}
@@ -1156,7 +1279,7 @@ def main():
           ach = traffic / (search_ms / 1e3) / 1e9
           req_s = pmc["rdreq"] / pmc["reads"] * args.reads / (search_ms / 1e3)
           roof.update({
-              "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+              "achieved": None, "frac": None, "achieved_counter_traffic": ach, "frac_counter_traffic": ach / HBM_PEAK_GBS, "traffic": traffic,
               "traffic_source": pmc["source"], "kernel_source_sha_now": kernel_source_sha(), "kernel_source_sha_of_profile": pmc.get("kernel_source_sha"),
               "fabric_read_requests_per_read": pmc["rdreq"] / pmc["reads"], "bytes_per_read_request": BYTES_PER_RANDOM_REQUEST,
               "calibration": "profiles/r2a_gather_calib.json: random 16-byte gathers from a 32 GB table, 1.00 request per touched 128-byte line "
@@ -1175,23 +1298,26 @@ def main():
               roof["frac_kernel_alone"] = traffic / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS
               roof["kernel_ms_alone"] = alone_ms
           roof["l2_hit"] = pmc.get("l2_hit")
-          roof["frac_counter_traffic"] = roof["frac"]
           if pmc.get("prof"):
               pr = pmc["prof"]
-              useful = (16 * (pr.get("table", 0) + pr.get("table10", 0)) + 48 * pr.get("ext_two_records", 0) + 24 * (pr.get("ext", 0) - pr.get("ext_two_records", 0))
-                        + 16 * pr.get("text_rows", 0) + 16 * pr.get("sa", 0) + 64 * pr.get("saw", 0) + 32 * pr.get("text_hits", 0) + 16 * pr.get("block_loads", 0) + 32 * c.get("hits", 0) / ns)
+              useful = useful_bytes_per_read(pr, c.get("hits", 0) / ns)
               roof["useful_bytes_per_read"] = useful
               roof["iteration_mix_per_read"] = pr
               roof["fetched_over_useful"] = (per_read_rd + per_read_wr) / useful if useful else None
-              roof["frac_useful_bytes"] = (useful * args.reads / (search_ms / 1e3) / 1e9) / HBM_PEAK_GBS
+              roof["achieved"] = useful * args.reads / (search_ms / 1e3) / 1e9          # the plain pair achieved / frac = USEFUL bytes
+              roof["frac_useful_bytes"] = roof["achieved"] / HBM_PEAK_GBS
+              roof["frac"] = roof["frac_useful_bytes"]
       else:
-          roof.update({"achieved": None, "frac": None, "traffic": None, "note": "no PMC source available (rocprofv3 failed and no committed profile for this workload)"})
-      # ONE place for the three yardsticks: `frac` / frac_counter_traffic = bytes the counters saw cross the fabric
-      # (128-byte lines) over the HBM peak; frac_useful_bytes = the bytes of those lines the kernel consumes; x_reference_algorithm =
+          roof.update({"achieved": None, "frac": None, "achieved_counter_traffic": None, "frac_counter_traffic": None, "traffic": None,
+                       "note": "no PMC source available (rocprofv3 failed and no committed profile for this workload)"})
+      # ONE place for the yardsticks: achieved / frac = frac_useful_bytes = the bytes of the fetched lines the kernel
+      # consumes over its time; frac_counter_traffic = bytes the counters saw cross the fabric (128-byte lines); x_reference_algorithm =
       # SURVEY.md section 8(d)'s algorithmic bytes of the REFERENCE's data structures over this kernel's time, as a multiple of the
       # peak (> 1: the kernel does not perform that memory work - K-mer table, text mode, step function replace it; results identical)
       roof["x_reference_algorithm"] = ref_alg_gbs / HBM_PEAK_GBS
-      roof["yardsticks"] = ("frac = frac_counter_traffic: fabric bytes by PMC / 8 TB/s; frac_useful_bytes: bytes consumed / 8 TB/s; x_reference_algorithm: "
+      roof["yardsticks"] = ("achieved / frac = frac_useful_bytes: bytes of the fetched lines the kernel consumes / kernel time (/ 8 TB/s); achieved_counter_traffic / "
+                            "frac_counter_traffic: fabric bytes by PMC (TCC_EA0_RDREQ x 128 B + WRITE_SIZE) / kernel time; gather.frac: fabric requests per second / "
+                            "the 48 G/s this chip sustains for dependent random gathers; l2_hit: TCC_HIT / (TCC_HIT + TCC_MISS); x_reference_algorithm: "
                             "SURVEY 8(d) bytes of the reference algorithm / kernel time / 8 TB/s (an algorithmic speed-up, not a bandwidth)")
       roof["reference_algorithm"] = {
           "bytes_per_read": bytes_search, "GBs_if_the_reference_traffic_were_moved": ref_alg_gbs, "x_of_hbm_peak": ref_alg_gbs / HBM_PEAK_GBS,
@@ -1376,6 +1502,9 @@ def main():
     del reads_d, reads2_d
     torch.cuda.empty_cache()
     out["roofline"] = build_roofline(live_pmc(args, cache, local_rank) if not args.no_pmc else None)    # (rank 0's GPU; the other ranks have left)
+    if not args.no_pmc and args.mode == "se":
+        out["post_stage"] = {"roofline": post_stage_roofline(live_pmc_post(args, cache, local_rank), args.reads, out["stage_ms"].get("tail_ms"),
+                                                             out["roofline"].get("fabric_read_requests_per_read"), c.get("hits", 0) / ns, c.get("locates", 0) / ns)}
     if not args.no_pmc and args.mode == "se" and not args.sub_result:
         out["with_device_sdust"]["roofline"] = dust_roofline(live_pmc_dust(args, cache, local_rank), args.reads, ms_with_dust - 1000.0 * elapsed / args.steps)
     if cli_job is not None:

@@ -30,8 +30,28 @@ class Cursor {
     }
   }
   ~Cursor() {
-    if (base_ && size_) munmap((void *)base_, size_);
+    if (base_ && size_ && !kept_) munmap((void *)base_, size_);
     if (fd_ >= 0) ::close(fd_);
+  }
+  // the mapping outlives the cursor: whoever holds the returned pointer keeps the file's pages reachable (RawWords::map)
+  std::shared_ptr<void> keep() {
+    if (!kept_ && base_ && size_) {
+      const size_t sz = size_;
+      kept_ = std::shared_ptr<void>((void *)base_, [sz](void *q) { munmap(q, sz); });
+    }
+    return kept_;
+  }
+  // n words at the cursor: left in the mapping when they are 8-byte aligned there (and the caller allows it), copied otherwise
+  void words(RawWords &w, size_t n, bool may_map, size_t extra_zero_words = 0) {
+    need(n * 8);
+    if (may_map && n && (reinterpret_cast<uintptr_t>(base_ + pos_) & 7u) == 0 && size_ - pos_ >= (n + extra_zero_words) * 8) {
+      w.map(reinterpret_cast<const uint64_t *>(base_ + pos_), n + extra_zero_words);     // (the words behind it: whatever the file holds there - see the caller)
+      pos_ += n * 8;
+      return;
+    }
+    uint64_t *dst = w.alloc(n + extra_zero_words);
+    for (size_t k = 0; k < extra_zero_words; ++k) dst[n + k] = 0;
+    copy(dst, n * 8);
   }
   template <class T> T get() {
     T v;
@@ -72,7 +92,14 @@ class Cursor {
   int fd_ = -1;
   const uint8_t *base_ = nullptr;
   size_t size_ = 0, pos_ = 0;
+  std::shared_ptr<void> kept_;
 };
+
+// CFR_INDEX_COPY=1 (a test / A-B switch behind CFR_DEBUG_ENV=1): every bit string copied into the process, as until round 4
+bool want_copies() {
+  const char *g = ::getenv("CFR_DEBUG_ENV"), *e = ::getenv("CFR_INDEX_COPY");
+  return g && atoi(g) != 0 && e && atoi(e) != 0;
+}
 
 inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
@@ -99,15 +126,14 @@ uint64_t parse_alphabet(Cursor &c, bool must_be_acgt) {
 }
 
 // BITVEC := u64 space | u64 n | i32 rb | i32 sb | i32 selectSpeed | i32 selectType | [B | RANK9 | SELECT]
-void parse_bitvector(Cursor &c, RawBitvector &bv) {
+void parse_bitvector(Cursor &c, RawBitvector &bv, bool may_map = false) {
   c.get<uint64_t>();
   bv.n = c.get<uint64_t>();
   c.skip(4 * sizeof(int32_t));
   if (bv.n == 0) return;
   uint64_t words = ceil_div(bv.n, 64);
-  bv.bits.resize(words);
   bv.file_off = c.pos();
-  c.copy(bv.bits.data(), words * 8);
+  c.words(bv.bits, words, may_map);
   c.get<uint64_t>();                        // rank9 _space
   uint64_t word_cnt = c.get<uint64_t>();
   if (word_cnt != words) throw FormatError{"rank9 word count mismatch"};
@@ -119,7 +145,7 @@ void parse_bitvector(Cursor &c, RawBitvector &bv) {
 }
 
 // WAVELET := SEQHDR | i32 nodeCnt | i32 selectSpeed | NODE*   ; SEQHDR := u64 space | u64 n | ALPHABET
-void parse_wavelet(Cursor &c, RawWavelet &w) {
+void parse_wavelet(Cursor &c, RawWavelet &w, bool may_map = false) {
   c.get<uint64_t>();
   w.n = c.get<uint64_t>();
   uint64_t asz = parse_alphabet(c, true);
@@ -133,7 +159,7 @@ void parse_wavelet(Cursor &c, RawWavelet &w) {
     c.get<int32_t>();       // prefixLen
     w.children[i][0] = c.get<int32_t>();
     w.children[i][1] = c.get<int32_t>();
-    parse_bitvector(c, w.node[i]);
+    parse_bitvector(c, w.node[i], may_map);
   }
   if (w.children[0][0] < 1 || w.children[0][0] > 2 || w.children[0][1] < 1 || w.children[0][1] > 2 ||
       w.children[0][0] == w.children[0][1])
@@ -176,10 +202,11 @@ void parse_fm(const std::string &path, HostIndex &h) {
   h.b = c.get<uint64_t>();
   h.block_cnt = c.get<uint64_t>();
   if (seq_n != h.n || h.b == 0 || h.block_cnt != ceil_div(h.n, h.b)) throw FormatError{"inconsistent run-block header"};
-  parse_bitvector(c, h.use_run_block);
+  const bool may_map = !want_copies();
+  parse_bitvector(c, h.use_run_block, may_map);
   if (h.use_run_block.n != h.block_cnt) throw FormatError{"useRunBlock length mismatch"};
-  parse_wavelet(c, h.wavelet_seq);
-  parse_wavelet(c, h.run_block_seq);
+  parse_wavelet(c, h.wavelet_seq, may_map);
+  parse_wavelet(c, h.run_block_seq, may_map);
   // alphabets + C[]
   parse_alphabet(c, true);
   uint64_t plain_n = parse_alphabet(c, true);
@@ -205,9 +232,9 @@ void parse_fm(const std::string &path, HostIndex &h) {
   h.sampled_n = c.get<uint64_t>();
   if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
   uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
-  h.sampled_words.resize(sw + 2);          // +2: device reads two words unconditionally
-  h.sampled_words[sw] = h.sampled_words[sw + 1] = 0;
-  c.copy(h.sampled_words.data(), sw * 8);
+  // +2: the device reads two words unconditionally and masks what it takes - zeros in a copy, the file's next 16 bytes (the ftab's
+  // first entry) in the mapping; no element's bits reach them
+  c.words(h.sampled_words, sw, may_map, 2);
   h.ftab.resize(2 * h.precompute_size);
   c.copy(h.ftab.data(), h.ftab.size() * 8);
   uint64_t max_lcp = c.get<uint64_t>();
@@ -225,6 +252,9 @@ void parse_fm(const std::string &path, HostIndex &h) {
   if (!c.eof()) h.has_end_marker = c.get<uint8_t>() != 0;   // absent in old indexes (FMIndex.hpp:178-181)
   if (h.has_end_marker) throw FormatError{"end-marker (protein) indexes are out of scope"};
   check_run_block_lengths(h);
+  const bool any_mapped = h.use_run_block.bits.mapped() || h.sampled_words.mapped() || h.wavelet_seq.node[0].bits.mapped() || h.wavelet_seq.node[1].bits.mapped() ||
+                          h.wavelet_seq.node[2].bits.mapped() || h.run_block_seq.node[0].bits.mapped() || h.run_block_seq.node[1].bits.mapped() || h.run_block_seq.node[2].bits.mapped();
+  if (any_mapped) h.file_mapping = c.keep();
 }
 
 // ---- protein index: FMIndex<Sequence_RunBlockOneTree>::Load (FMIndex.hpp:588-606, Sequence_RunBlockOneTree.hpp:499-513)
@@ -314,9 +344,7 @@ void parse_fm_protein(const std::string &path, HostIndex &h) {
   h.sampled_n = c.get<uint64_t>();
   if (h.sampled_bits <= 0 || h.sampled_bits > 64) throw FormatError{"bad sampledSA element width"};
   const uint64_t sw = ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64);
-  h.sampled_words.resize(sw + 2);
-  h.sampled_words[sw] = h.sampled_words[sw + 1] = 0;
-  c.copy(h.sampled_words.data(), sw * 8);
+  c.words(h.sampled_words, sw, false, 2);          // (a copy: the protein parser decodes everything into the process anyway)
   h.ftab.resize(2 * h.precompute_size);
   c.copy(h.ftab.data(), h.ftab.size() * 8);
   const uint64_t max_lcp = c.get<uint64_t>();

@@ -18,20 +18,37 @@
 
 namespace cfr {
 
-// words read straight from a file: a vector whose resize() does not zero-fill first (a 40 Gbp index holds 15 GB of them; the
-// fill was a single-threaded pass of its own in front of the copy)
+// Words of a bit string of the index.  Round 5: they stay where they are - in the read-only mapping of the .1.cfr file, which
+// HostIndex keeps for its lifetime - instead of being copied into this process (a 40 Gbp index holds 15 GB of them: eight ranks of one
+// node each made their own copy at once, 6.3 s per open against 2.5 s alone and 120 GB of host memory; mapped, the ranks share the
+// page cache's pages and an open costs the headers).  A string that is not 8-byte aligned in the file, and every caller that wants
+// its own (CFR_INDEX_COPY=1 behind CFR_DEBUG_ENV, the protein parser), gets a copy as before: a vector whose resize() does not
+// zero-fill first.
 template <class T> struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { using other = NoInitAlloc<U>; };
   template <class U, class... A> void construct(U *p, A &&...a) {
     if constexpr (sizeof...(A) == 0) ::new ((void *)p) U; else ::new ((void *)p) U(std::forward<A>(a)...);
   }
 };
-using RawWords = std::vector<uint64_t, NoInitAlloc<uint64_t>>;
+class RawWords {
+ public:
+  const uint64_t *data() const { return p_; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  const uint64_t &operator[](size_t i) const { return p_[i]; }
+  bool mapped() const { return n_ != 0 && own_.empty(); }
+  void map(const uint64_t *q, size_t n) { own_.clear(); p_ = q; n_ = n; }                       // n words at q, which outlive this object
+  uint64_t *alloc(size_t n) { own_.resize(n); p_ = own_.data(); n_ = n; return own_.data(); }   // n words of its own, not initialised
+ private:
+  const uint64_t *p_ = nullptr;
+  size_t n_ = 0;
+  std::vector<uint64_t, NoInitAlloc<uint64_t>> own_;
+};
 
 struct RawBitvector {          // Bitvector_Plain as stored (its DS_Rank9 blocks are checked for size and skipped: the device image
   uint64_t n = 0;              // bits                             counts its own rank lines)
   RawWords bits;               // ceil(n/64)
-  uint64_t file_off = 0;       // where the words stand in the .1.cfr file (the decode's forensics compare the copy with the file again)
+  uint64_t file_off = 0;       // where the words stand in the .1.cfr file (the decode's forensics compare a copy with the file again)
 };
 
 struct RawWavelet {            // Sequence_WaveletTree<Bitvector_Plain> for sigma=4: 3 nodes
@@ -92,6 +109,7 @@ struct HostIndex {
   Taxonomy tax;
   cfr_params params;
   int score_hit_len_adjust = 15;   // Classifier.hpp:848
+  std::shared_ptr<void> file_mapping;   // the .1.cfr file, mapped read-only: the RawWords above point into it (empty: every string is a copy)
 };
 
 // Throws std::runtime_error with a message; cfr_capi.cpp maps it to cfr_status.

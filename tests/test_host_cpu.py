@@ -525,3 +525,28 @@ def test_pack_reads_equals_the_definition():
         for j in range(16):        # code bits only where the character is a symbol
             ok = valid[v[:, j]] == 1
             assert np.array_equal(((got >> np.uint64(2 * j)) & np.uint64(3))[ok], code[v[:, j]][ok])
+
+
+def test_mapped_and_copied_opens_are_the_same_index(golden_dir, tmp_path):
+    """Round 5: cfr_index_open leaves the bit strings in the read-only mapping of the .1.cfr file (the ranks of one node share the page
+    cache's pages) where round 4 copied them into the process; CFR_INDEX_COPY=1 is the old form.  Same digest, same host tail; and the
+    mapped index keeps working after the file's NAME is gone (the mapping holds the inode)."""
+    import shutil
+    for iname in ("f6", "f6_b1", "f10"):
+        src = os.path.join(golden_dir, iname)
+        a = capi.Index(src, capi.default_params())
+        os.environ["CFR_INDEX_COPY"] = "1"
+        try:
+            b = capi.Index(src, capi.default_params())
+        finally:
+            del os.environ["CFR_INDEX_COPY"]
+        assert a.digest() == b.digest()
+        a.close(); b.close()
+    for k in (1, 2, 4):
+        shutil.copy(os.path.join(golden_dir, f"f6.{k}.cfr"), tmp_path / f"gone.{k}.cfr")
+    idx = capi.Index(str(tmp_path / "gone"), capi.default_params())
+    want = idx.digest()
+    for k in (1, 2, 4):
+        os.unlink(tmp_path / f"gone.{k}.cfr")
+    assert idx.digest() == want
+    idx.close()
