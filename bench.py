@@ -352,7 +352,7 @@ def live_pmc_dust(args, cache, gpu=0):
 
 
 def dust_roofline(pm, reads, dust_ms):
-    """The SDUST kernel is bound by its own instruction stream: its roofline is the VALU issue rate.  A wave64
+    """The SDUST kernel is bound by its own instruction stream (profiles/HISTORY.md section 4): its roofline is the VALU issue rate.  A wave64
     VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md, wave scheduling), so peak = 1024 SIMDs x clock / 2
     wave-instructions per second; clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / kernel time when that counter came back."""
     if not pm:

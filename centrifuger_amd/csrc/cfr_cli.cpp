@@ -23,6 +23,7 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -126,6 +127,7 @@ bool ByteBuf::use_pinned = false;     // measured: hipHostMalloc of 40 MB per ba
 class SeqReader {
  public:
   explicit SeqReader(const std::vector<std::string> &files) : files_(files), buf_(1u << 24) {}
+  static int inflate_threads;          // threads that inflate the blocks of a BGZF file side by side (1: every .gz through gzread)
   // a byte range of a memory-mapped plain file that starts at a record header (the parallel path: ParallelFiles below)
   SeqReader(const char *mem, size_t len) : mem_(mem), pos_(0), end_(len), eof_(true) {}
   ~SeqReader() { close_file(); }
@@ -138,16 +140,19 @@ class SeqReader {
   // returns false at the end of all files
   bool next(std::vector<char> *ids, ByteBuf &seq, std::vector<char> *qual, bool &has_qual) {
     for (;;) {
-      if (!fp_) {
+      if (!fp_ && !bgzf_base_) {
         if (file_idx_ >= files_.size()) return false;
         const std::string &f = files_[file_idx_++];
-        fp_ = f == "-" ? gzdopen(fileno(stdin), "r") : gzopen(f.c_str(), "r");
-        if (!fp_) { print_log("ERROR: cannot open read file %s", f.c_str()); exit(EXIT_FAILURE); }
-        gzbuffer(fp_, 1 << 20);
         have_header_ = false;
         pos_ = end_ = 0;
         eof_ = false;
-        start_inflater();
+        if (f != "-" && inflate_threads > 1 && open_bgzf(f)) start_bgzf_inflaters();
+        else {
+          fp_ = f == "-" ? gzdopen(fileno(stdin), "r") : gzopen(f.c_str(), "r");
+          if (!fp_) { print_log("ERROR: cannot open read file %s", f.c_str()); exit(EXIT_FAILURE); }
+          gzbuffer(fp_, 1 << 20);
+          start_inflater();
+        }
       }
       if (read_record(ids, seq, qual, has_qual)) return true;
       close_file();
@@ -240,7 +245,135 @@ class SeqReader {
       }
     });
   }
+  // ---- BGZF (bgzip, htslib): a .gz file made of independent deflate blocks of at most 64 KB whose compressed size stands in an extra
+  // field of every block's header ('B' 'C', RFC 1952 FEXTRA; SAM specification section 4.1) - so the blocks can be found without
+  // inflating anything, and inflated side by side.  The reference reads such a file like any .gz (kseq + gzread, ReadFiles.hpp:337): one
+  // thread, ~0.4 GB/s of text; here a dispatcher walks the headers, groups of blocks (~8 MB of text) are inflated by inflate_threads
+  // workers (raw inflate + CRC-32 + ISIZE of every block checked, like gzread does) and handed to the line splitter in file order.
+  static bool bgzf_header(const uint8_t *b, size_t left, size_t &bsize) {        // b: start of a block; false: not a BGZF block
+    if (left < 18 || b[0] != 0x1f || b[1] != 0x8b || b[2] != 8 || !(b[3] & 4)) return false;
+    const size_t xlen = (size_t)b[10] | ((size_t)b[11] << 8);
+    if (12 + xlen > left) return false;
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+      const size_t slen = (size_t)b[o + 2] | ((size_t)b[o + 3] << 8);
+      if (b[o] == 'B' && b[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+        bsize = ((size_t)b[o + 4] | ((size_t)b[o + 5] << 8)) + 1;
+        return bsize >= 12 + xlen + 8 && bsize <= left;
+      }
+      o += 4 + slen;
+    }
+    return false;
+  }
+  bool open_bgzf(const std::string &path) {
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    uint8_t magic[4];
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28 || pread(fd, magic, 4, 0) != 4 || magic[0] != 0x1f || magic[1] != 0x8b ||
+        magic[2] != 8 || !(magic[3] & 4)) { ::close(fd); return false; }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return false;
+    size_t bs = 0;
+    if (!bgzf_header((const uint8_t *)m, (size_t)st.st_size, bs)) { munmap(m, (size_t)st.st_size); return false; }    // a .gz with another extra field
+    bgzf_base_ = (const uint8_t *)m;
+    bgzf_size_ = (size_t)st.st_size;
+    bgzf_path_ = path;
+    return true;
+  }
+  struct BgzfTask { size_t id, off, end, text; };                               // blocks [off, end) of the file inflate to `text` bytes
+  void start_bgzf_inflaters() {
+    inf_stop_ = false;
+    inf_eof_ = false;
+    bgzf_next_deliver_ = 0;
+    bgzf_issued_ = 0;
+    bgzf_tasks_done_ = false;
+    const int nt = inflate_threads;
+    bgzf_workers_.emplace_back([this, nt]() {                                     // the dispatcher
+      size_t off = 0, id = 0;
+      while (off < bgzf_size_) {
+        BgzfTask t{id, off, off, 0};
+        while (t.end < bgzf_size_ && t.text < (8u << 20)) {
+          size_t bs = 0;
+          if (!bgzf_header(bgzf_base_ + t.end, bgzf_size_ - t.end, bs)) { print_log("ERROR: %s is not a well-formed BGZF file at byte %lu", bgzf_path_.c_str(), (unsigned long)t.end); exit(EXIT_FAILURE); }
+          const uint8_t *tail = bgzf_base_ + t.end + bs - 4;
+          t.text += (size_t)tail[0] | ((size_t)tail[1] << 8) | ((size_t)tail[2] << 16) | ((size_t)tail[3] << 24);
+          t.end += bs;
+        }
+        off = t.end;
+        std::unique_lock<std::mutex> lk(inf_mu_);
+        inf_cv_.wait(lk, [&] { return inf_stop_ || bgzf_issued_ - bgzf_next_deliver_ < (size_t)(2 * nt + 2); });
+        if (inf_stop_) return;
+        bgzf_queue_.push_back(t);
+        ++bgzf_issued_;
+        ++id;
+        inf_cv_.notify_all();
+      }
+      std::lock_guard<std::mutex> lk(inf_mu_);
+      bgzf_tasks_done_ = true;
+      inf_cv_.notify_all();
+    });
+    for (int w = 0; w < nt; ++w) bgzf_workers_.emplace_back([this]() {
+      z_stream zs;
+      memset(&zs, 0, sizeof(zs));
+      if (inflateInit2(&zs, -15) != Z_OK) { print_log("ERROR: zlib inflateInit2 failed"); exit(EXIT_FAILURE); }
+      for (;;) {
+        BgzfTask t;
+        {
+          std::unique_lock<std::mutex> lk(inf_mu_);
+          inf_cv_.wait(lk, [&] { return inf_stop_ || !bgzf_queue_.empty() || bgzf_tasks_done_; });
+          if (inf_stop_ || bgzf_queue_.empty()) break;
+          t = bgzf_queue_.front();
+          bgzf_queue_.pop_front();
+        }
+        Chunk c;
+        c.data.resize(t.text);
+        size_t out = 0;
+        for (size_t o = t.off; o < t.end;) {
+          size_t bs = 0;
+          bgzf_header(bgzf_base_ + o, bgzf_size_ - o, bs);
+          const uint8_t *b = bgzf_base_ + o;
+          const size_t xlen = (size_t)b[10] | ((size_t)b[11] << 8), hdr = 12 + xlen;
+          const uint8_t *tail = b + bs - 8;
+          const uint32_t crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+          const size_t isize = (size_t)tail[4] | ((size_t)tail[5] << 8) | ((size_t)tail[6] << 16) | ((size_t)tail[7] << 24);
+          inflateReset(&zs);
+          zs.next_in = const_cast<Bytef *>(b + hdr);
+          zs.avail_in = (uInt)(bs - hdr - 8);
+          zs.next_out = (Bytef *)c.data.data() + out;
+          zs.avail_out = (uInt)isize;
+          const int rc = isize || zs.avail_in > 2 ? inflate(&zs, Z_FINISH) : Z_STREAM_END;
+          if ((rc != Z_STREAM_END && !(rc == Z_OK && zs.avail_out == 0)) || zs.total_out != isize ||
+              (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)c.data.data() + out, (uInt)isize) != crc) {
+            print_log("ERROR: %s: a BGZF block at byte %lu does not inflate to what its trailer says", bgzf_path_.c_str(), (unsigned long)o);
+            exit(EXIT_FAILURE);
+          }
+          out += isize;
+          o += bs;
+        }
+        std::lock_guard<std::mutex> lk(inf_mu_);
+        bgzf_done_.emplace(t.id, std::move(c));
+        inf_cv_.notify_all();
+      }
+      inflateEnd(&zs);
+    });
+  }
+  size_t pull_bgzf(char *dst, size_t cap) {
+    std::unique_lock<std::mutex> lk(inf_mu_);
+    for (;;) {
+      inf_cv_.wait(lk, [&] { return bgzf_done_.count(bgzf_next_deliver_) || (bgzf_tasks_done_ && bgzf_next_deliver_ == bgzf_issued_); });
+      auto it = bgzf_done_.find(bgzf_next_deliver_);
+      if (it == bgzf_done_.end()) return 0;
+      Chunk &c = it->second;
+      const size_t n = std::min(cap, c.data.size() - c.used);
+      memcpy(dst, c.data.data() + c.used, n);
+      c.used += n;
+      if (c.used == c.data.size()) { bgzf_done_.erase(it); ++bgzf_next_deliver_; inf_cv_.notify_all(); }
+      if (n) return n;                                                           // (an empty group - the end-of-file marker block - is skipped)
+    }
+  }
   size_t pull(char *dst, size_t cap) {                    // up to cap bytes of decompressed text; 0 at the end of the file
+    if (bgzf_base_) return pull_bgzf(dst, cap);
     std::unique_lock<std::mutex> lk(inf_mu_);
     inf_cv_.wait(lk, [&] { return !ready_.empty() || inf_eof_; });
     if (ready_.empty()) return 0;
@@ -257,10 +390,26 @@ class SeqReader {
       inf_cv_.notify_all();
       inflater_.join();
     }
+    if (!bgzf_workers_.empty()) {
+      { std::lock_guard<std::mutex> lk(inf_mu_); inf_stop_ = true; }
+      inf_cv_.notify_all();
+      for (auto &t : bgzf_workers_) t.join();
+      bgzf_workers_.clear();
+      bgzf_queue_.clear();
+      bgzf_done_.clear();
+    }
+    if (bgzf_base_) { munmap((void *)bgzf_base_, bgzf_size_); bgzf_base_ = nullptr; bgzf_size_ = 0; }
     ready_.clear();
     if (fp_) gzclose(fp_);
     fp_ = nullptr;
   }
+  const uint8_t *bgzf_base_ = nullptr;
+  size_t bgzf_size_ = 0, bgzf_next_deliver_ = 0, bgzf_issued_ = 0;
+  bool bgzf_tasks_done_ = false;
+  std::string bgzf_path_;
+  std::vector<std::thread> bgzf_workers_;
+  std::deque<BgzfTask> bgzf_queue_;
+  std::map<size_t, Chunk> bgzf_done_;
   std::thread inflater_;
   std::mutex inf_mu_;
   std::condition_variable inf_cv_;
@@ -276,6 +425,8 @@ class SeqReader {
   std::string header_;
   bool have_header_ = false;
 };
+
+int SeqReader::inflate_threads = 1;
 
 // A plain (not gz) regular read file mapped into memory, and the offsets at which it can be cut into independently parsable
 // pieces.  A cut is a verified record start: FASTA - a line that starts with '>'; FASTQ - a line that starts with '@' whose
@@ -622,6 +773,7 @@ int main(int argc, char *argv[]) {
   print_log("Centrifuger-MI355X (%s) starts.", cfr_version());
   if (opt.idx.empty()) { print_log("Need to use -x to specify index prefix."); return EXIT_FAILURE; }
   if (opt.threads < 1) opt.threads = 1;
+  SeqReader::inflate_threads = std::max(1, std::min(opt.threads, 16));
   if (opt.gpu_batch < 1) opt.gpu_batch = 1;
   const bool paired = !opt.m1.empty() || !opt.inter.empty();
   if (opt.m1.size() != opt.m2.size()) { print_log("ERROR: -1 and -2 must be given the same number of times."); return EXIT_FAILURE; }

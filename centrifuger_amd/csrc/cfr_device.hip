@@ -24,7 +24,7 @@ inline void hip_check(hipError_t e, const char *what) {
 }
 #define HIP_CHECK(x) hip_check((x), #x)
 
-// The CFR_* switches of DESIGN.md section 5 are A/B and test hooks, not part of the library's interface: they are only
+// The CFR_* switches of profiles/HISTORY.md section 5 are A/B and test hooks, not part of the library's interface: they are only
 // looked at when CFR_DEBUG_ENV=1 is set in the environment (one documented gate; a production caller never sets it and
 // the library then has no hidden inputs - everything a caller chooses goes through cfr_device_options).
 inline const char *dbg_env(const char *name) {
@@ -78,7 +78,9 @@ DeviceIndex::DeviceIndex(const HostIndex &h, int device, const cfr_device_option
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"no HIP device available (libcfr_hip has no CPU fallback)", -1};
   if (device < 0 || device >= count) throw HipError{"device ordinal out of range", -1};
-  if (h.params.max_result > 64) throw HipError{"-k / max_result above 64 is not supported by the device tail", -2};
+  // (-k has no cap in the reference, Classifier.hpp:17-38, 738-781.  The device tail has none either since round 5 - its listings are
+  // arrays in pool scratch or a team's slot list - but the match buffers are max_result slots per read: 4096 keeps a sub-batch's below 100 GB)
+  if (h.params.max_result > 4096) throw HipError{"-k / max_result above 4096: the match buffers (max_result slots per read) would not fit beside the index", -2};
   try {
     init(h, opt);
   } catch (...) {
@@ -1220,6 +1222,8 @@ std::vector<std::pair<size_t, size_t>> DeviceIndex::cut_pieces(size_t n, bool pe
   // 5.7e6 in twelve)
   const size_t kTaperMax = 4;
   size_t want = sub_batch_;
+  if (per_read_slots && view_.max_result > 16)            // two sets of max_result 24-byte match slots per read: at most ~8 GB of them
+    want = std::max<size_t>(4096, std::min<size_t>(want, (size_t)(8e9 / (48.0 * (double)view_.max_result))));
   if (n && total_bases && (double)want * ((double)total_bases / (double)n) > (double)piece_bases_max_)
     want = std::max<size_t>(1, (size_t)((double)piece_bases_max_ / ((double)total_bases / (double)n)));
   sb = per_read_slots ? std::max(want, (n + (kMaxSub - kTaperMax) - 1) / (kMaxSub - kTaperMax)) : n;   // row-space matches: one piece

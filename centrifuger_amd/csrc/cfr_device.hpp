@@ -1,6 +1,6 @@
 // cfr_device.hpp — the index image in HBM and the batch pipeline that runs on it (gfx950).
 //
-// Data layout:
+// Data layout (profiles/HISTORY.md §3):
 //   occ      : one 64-byte record per 128 BWT symbols
 //                u64 mid[4]   #c in B[0 .. 128*r + 64)      (bit 63 of mid[0]: record holds a selectedSA row)
 //                u64 lo0, hi0 bit planes of symbols   0..63  (bit k of lo = low code bit of symbol k)

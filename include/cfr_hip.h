@@ -127,7 +127,7 @@ cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_ind
 
 /* What the device image is built with.  Nothing here changes a result; it trades load time and HBM for throughput.
  * cfr_device_index_create == cfr_device_index_create_ex with the defaults.  (The CFR_* environment variables listed in
- * DESIGN.md section 5 override these fields when set: they exist for A/B runs and for the variant tests.) */
+ * profiles/HISTORY.md section 5 override these fields when set: they exist for A/B runs and for the variant tests.) */
 typedef enum { CFR_PROFILE_THROUGHPUT = 0, CFR_PROFILE_FAST_LOAD = 1, CFR_PROFILE_BALANCED = 2 } cfr_profile;
 typedef struct {
   int32_t profile;        /* cfr_profile.  FAST_LOAD: K-mer table of at most 4^13 entries, no text-mode tables, no locate memo

@@ -105,6 +105,7 @@ OPTION_SETS = {
     "hitk1": ["--hitk-factor", "1"],
     "hitk_negative_k2": ["--hitk-factor", "-1", "-k", "2"],
     "k64": ["-k", "64"],
+    "k200": ["-k", "200"],                                        # (the reference has no cap on -k; round 4 refused anything above 64)
 }
 
 

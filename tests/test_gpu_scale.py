@@ -464,3 +464,34 @@ def test_submitted_batches_equal_the_blocking_call_and_one_call_at_a_time(world)
         ref_small = ref_small or digest(*canon(*r, k))
         assert digest(*canon(*r, k)) == ref_small
     dev.close()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "centrifuger")),
+                    reason="oracle/_ref (compiled reference) not present")
+def test_k_above_64_lists_every_strain_like_the_reference(tmp_path):
+    """-k 100 over families of 90 near-identical strains: a read lists up to 90 sequences (more slots than any register or team
+    table holds: the single-lane form with pool scratch), and the reference has no cap on -k (Classifier.hpp:17-38).  TSV of 3000
+    reads and 1000 pairs == the reference binary's; -k 4097 is refused before any device work."""
+    import subprocess
+    import torch
+    from centrifuger_amd import indexbuild
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = synth.make_genomes(2, 90, 20_000, seed=3301, divergence_step=0.0002)
+    prefix = str(tmp_path / "idx")
+    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    rs = synth.make_reads(g, 3000, 150, seed=3302, sub_rate=0.003, n_rate=0.0005)
+    r1, r2 = synth.make_pairs(g, 1000, 125, seed=3303)
+    synth.write_fastq(rs, str(tmp_path / "r.fq"))
+    synth.write_fastq(r1, str(tmp_path / "p_1.fq"), suffix="/1"); synth.write_fastq(r2, str(tmp_path / "p_2.fq"), suffix="/2")
+    ref = os.path.join(root, "oracle", "_ref", "centrifuger")
+    cli = os.path.join(root, "centrifuger_amd", "bin", "centrifuger")
+    most = 0
+    for reads in (["-u", str(tmp_path / "r.fq")], ["-1", str(tmp_path / "p_1.fq"), "-2", str(tmp_path / "p_2.fq")]):
+        want = subprocess.run([ref, "-x", prefix, "-t", "8", "-k", "100"] + reads, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        for extra in ([], ["--gpu-throughput"]):
+            got = subprocess.run([cli, "-x", prefix, "-t", "4", "-k", "100"] + reads + extra, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+            assert got == want, (reads[0], extra)
+        most = max(most, max(int(ln.split(b"\t")[7]) for ln in want.split(b"\n")[1:-1]))
+    assert most > 64, most
+    with pytest.raises(capi.CfrError):
+        capi.DeviceIndex(capi.Index(prefix, capi.default_params(max_result=4097)))

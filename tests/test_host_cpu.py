@@ -550,3 +550,51 @@ def test_mapped_and_copied_opens_are_the_same_index(golden_dir, tmp_path):
         os.unlink(tmp_path / f"gone.{k}.cfr")
     assert idx.digest() == want
     idx.close()
+
+
+def write_bgzf(path, data, block=0xff00, level=1, eof_marker=True):
+    """a BGZF file (bgzip's format, SAM specification 4.1): independent deflate blocks, each a gzip member whose extra field 'BC'
+    carries the member's size"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        pieces = [data[o:o + block] for o in range(0, len(data), block)] + ([b""] if eof_marker else [])
+        for piece in pieces:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            comp = co.compress(piece) + co.flush()
+            bsize = 12 + 6 + len(comp) + 8
+            f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+            f.write(comp + struct.pack("<II", zlib.crc32(piece) & 0xffffffff, len(piece)))
+
+
+def test_bgzf_input_is_inflated_by_several_threads(tmp_path):
+    """A bgzip'd read file: the blocks are inflated side by side (-t > 1) and reach the line splitter in file order; the same records
+    as the plain file and as the same file through gzread (-t 1); a damaged block is an error, not a silent gap."""
+    import gzip
+    import subprocess
+    cli = os.path.join(ROOT, "centrifuger_amd", "bin", "centrifuger")
+    if not os.path.exists(cli):
+        pytest.skip("CLI not built")
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(60000):
+        n = int(rng.integers(30, 260))
+        recs.append(b"@r%d/1 x\n%s\n+\n%s\n" % (i, bytes(rng.choice(list(b"ACGTN"), size=n).astype(np.uint8)), b"I" * n))
+    data = b"".join(recs)                                  # ~19 MB: three groups of blocks
+    (tmp_path / "plain.fq").write_bytes(data)
+    write_bgzf(tmp_path / "reads.fq.gz", data)
+    assert gzip.open(tmp_path / "reads.fq.gz", "rb").read() == data          # (what any gzip reader makes of it)
+    env = dict(os.environ, CFR_CLI_PARSE_ONLY="1")
+    run = lambda f, t: subprocess.run([cli, "-x", "unused", "-u", str(f), "-t", str(t)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    want = run(tmp_path / "plain.fq", 1).stdout
+    assert want.count(b"\n") == 60000
+    for t in (1, 2, 8, 64):
+        r = run(tmp_path / "reads.fq.gz", t)
+        assert r.returncode == 0 and r.stdout == want, t
+    write_bgzf(tmp_path / "tiny.fq.gz", data[:1000], block=100, eof_marker=False)      # many small blocks, no end-of-file marker
+    assert run(tmp_path / "tiny.fq.gz", 8).stdout == run(tmp_path / "tiny.fq.gz", 1).stdout != b""
+    bad = bytearray((tmp_path / "reads.fq.gz").read_bytes())
+    bad[len(bad) // 2] ^= 0x55
+    (tmp_path / "bad.fq.gz").write_bytes(bytes(bad))
+    r = run(tmp_path / "bad.fq.gz", 8)
+    assert r.returncode != 0 and b"BGZF" in r.stderr

@@ -1,7 +1,7 @@
 """Registers and scratch memory of the hot kernels, checked where the build happens (hipcc cross-compiles gfx950 without a GPU).
 
 A private array the compiler makes of an if-chain is invisible in the source and in the register count, and one of them sat in the
-text step of k_search_chains_v2 for three rounds (20 bytes of scratch, 11 % of the step: DESIGN.md section 4).  This test compiles
+text step of k_search_chains_v2 for three rounds (20 bytes of scratch, 11 % of the step: profiles/HISTORY.md section 4).  This test compiles
 probe translation units that instantiate the kernels of csrc/cfr_kernels.hip.inc exactly as csrc/cfr_device.hip launches them
 (`hipcc --cuda-device-only -Rpass-analysis=kernel-resource-usage`, four probes side by side) and fails when one of them
  * has scratch memory where its budget says none (or more than the true spills recorded here), or

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the cheap probes of rounds 3 / 4 once more on the search kernel WITHOUT its scratch array (cfg2; "pe" = pairs -k 5)
+# profiles/HISTORY.md section 8 item 0: the cheap probes of rounds 3 / 4 once more on the search kernel WITHOUT its scratch array (cfg2; "pe" = pairs -k 5)
 export CFR_DEBUG_ENV=1
 run() { python bench.py "$@" --no-cpu-baseline --no-pmc --no-extra-configs --steps 6 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('%.4g /s  search %.2f ms  post %.2f ms  total %.2f ms  step %.2f ms' % (d['value'], d['stage_ms']['search_ms'], d['stage_ms']['tail_ms'], d['stage_ms']['total_ms'], d['ms_per_step']))"; }
 probe() { echo -n "$1 | cfg2: "; env $1 bash -c "$(declare -f run); run"; }
