@@ -605,6 +605,16 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       }
       if (const char *e = dbg_env("CFR_TEXT_MIN_L")) view_.text_min_l = (uint32_t)atoi(e);
       lap("locate step function");
+      // K-mer entries of one row carry the row's text position (k_ftabx_textpos): the search then skips its suffix-array fetch.
+      // Only where such a search would move to the text right behind the table (K >= text_min_l) and the entries have the room (16 bytes).
+      static const bool tp_off = dbg_env("CFR_FTABX_TEXTPOS") && atoi(dbg_env("CFR_FTABX_TEXTPOS")) == 0;
+      if (!protein && !tp_off && view_.ftabx && !view_.ftabx_e8 && view_.ftabx_width >= view_.text_min_l && (view_.sa32 || view_.sa36)) {
+        const uint64_t entries = 1ull << (2 * view_.ftabx_width);
+        k_ftabx_textpos<<<(unsigned)std::min<uint64_t>((entries + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, view_.ftabx_width, const_cast<uint64_t *>(view_.ftabx));
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        lap("text positions into the K-mer table");
+      }
     } catch (const HipError &) {                           // optional tables: run without them, and give back what they took
       (void)hipGetLastError();
       (void)hipStreamSynchronize(stream_);
