@@ -1531,6 +1531,40 @@ def main():
                                           "the like-for-like ratio"}
             except Exception as e:
                 out["e2e_cli"] = {"error": repr(e)}
+            # ---- steady state: cfg4's read count (100 M) through the command line - the sample file back to back (the ids repeat, so the
+            # rows are the reference's rows of the sample, repeated); a run of a few seconds in which the index load no longer dominates
+            if world == 1 and args.mode == "se" and not paired and not args.sub_result and len(files) == 2 and not args.no_extra_configs:
+                try:
+                    import hashlib
+                    reps = max(1, 100_000_000 // nb)
+                    big = os.path.join(cache, "e2e_100m.fa")
+                    with open(big, "wb") as fo:
+                        blob = open(files[1], "rb").read()
+                        for _ in range(reps):
+                            fo.write(blob)
+                    del blob
+                    tsv_path = os.path.join(cache, "e2e_100m.tsv")
+                    t0 = time.time()
+                    with open(tsv_path, "wb") as fo:
+                        subprocess.run([cli, "-x", prefix, "-t", str(min(ncpu, 64)), "-k", str(k), "-u", big], check=True, stdout=fo, stderr=subprocess.DEVNULL)
+                    t_big = time.time() - t0
+                    h_got = hashlib.md5()
+                    with open(tsv_path, "rb") as fi:
+                        for chunk in iter(lambda: fi.read(1 << 24), b""):
+                            h_got.update(chunk)
+                    head, _, rows = ref_tsv.partition(b"\n")
+                    h_want = hashlib.md5(head + b"\n")
+                    for _ in range(reps):
+                        h_want.update(rows)
+                    out["e2e_cli_100m"] = {"reads": nb * reps, "seconds": t_big, "value": nb * reps / t_big, "unit": "reads/s",
+                                           "md5_equals_reference_rows": h_got.hexdigest() == h_want.hexdigest(),
+                                           "reference_reads_per_s": nb / t_full, "speedup": (nb * reps / t_big) / (nb / t_full),
+                                           "note": "wall clock of `centrifuger -x idx -u 100M.fa -t 64 > file` (process start, index load, device image, parse, SDUST on the "
+                                                   "device, classify, TSV); the reference's rate is its run on the sample (it scales linearly in reads)"}
+                    os.unlink(big)
+                    os.unlink(tsv_path)
+                except Exception as e:
+                    out["e2e_cli_100m"] = {"error": repr(e)}
     # ---- the other BASELINE configs on the same index, as sub-results (configs[2] paired-end -k 5, configs[4]-style long reads)
     if world == 1 and args.mode == "se" and not args.no_extra_configs and not args.inner:
         out["other_configs"] = {}

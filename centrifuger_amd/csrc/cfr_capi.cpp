@@ -557,32 +557,40 @@ size_t cfr_format_tsv_expanded(const cfr_index *idx, const char *read_id, const 
 
 static size_t format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches, bool expanded, const cfr_span *spans,
                          const uint64_t *ids, char *buf, size_t cap) {
-  // ResultWriter::Output (ResultWriter.hpp:209-240); expanded: PrintExtraCol(expandedTaxIdStrings[i]) / PrintExtraCol("") (:226-227, :239-240)
-  size_t off = 0;
-  auto put = [&](int w) { if (w > 0) off += (size_t)w; };
+  // ResultWriter::Output (ResultWriter.hpp:209-240): "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d" + PrintExtraCol(expandedTaxIdStrings[i]) / PrintExtraCol("")
+  // (:226-227, :239-240) - the same bytes, put together by hand: at a hundred million rows per run snprintf's format parsing was the
+  // command line's slowest stage (profiles/r5_cli_timing_100m.txt)
+  struct Out {
+    char *buf; size_t cap, off;
+    void put(const char *p, size_t n) { if (buf && off < cap) memcpy(buf + off, p, n < cap - off ? n : cap - off); off += n; }
+    void ch(char c) { if (buf && off < cap) buf[off] = c; ++off; }
+    void u64(uint64_t v) { char t[24]; int k = 24; do { t[--k] = (char)('0' + v % 10); v /= 10; } while (v); put(t + k, (size_t)(24 - k)); }
+    void i32(int32_t v) { if (v < 0) { ch('-'); u64((uint64_t)(-(int64_t)v)); } else u64((uint64_t)v); }
+  } o{buf, cap, 0};
   const cfr::Taxonomy &t = idx->h->tax;
+  const size_t idn = strlen(read_id);
   if (r->n_match > 0) {
     for (int i = 0; i < r->n_match; ++i) {
       const cfr_match &m = matches[r->match_begin + (uint64_t)i];
       const char *name;
       if (m.kind == 0) name = m.id < t.seq_name.size() ? t.seq_name[m.id].c_str() : "";
       else name = cfr::tax_rank_string(m.id < t.node_cnt ? t.rank[m.id] : 0);
-      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "%s\t%s\t%lu\t%lu\t%lu\t%d\t%d\t%d", read_id,
-                   name, (unsigned long)m.taxid, (unsigned long)r->score, (unsigned long)r->secondary_score, r->hit_length,
-                   r->query_length, r->n_match));
+      o.put(read_id, idn); o.ch('\t'); o.put(name, strlen(name)); o.ch('\t'); o.u64(m.taxid); o.ch('\t'); o.u64(r->score); o.ch('\t');
+      o.u64(r->secondary_score); o.ch('\t'); o.i32(r->hit_length); o.ch('\t'); o.i32(r->query_length); o.ch('\t'); o.i32(r->n_match);
       if (expanded) {
-        put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "\t"));
+        o.ch('\t');
         const cfr_span sp = spans ? spans[r->match_begin + (uint64_t)i] : cfr_span{0, 0};
-        for (uint64_t j = 0; j < sp.count; ++j)
-          put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, j ? ",%lu" : "%lu", (unsigned long)ids[sp.begin + j]));
+        for (uint64_t j = 0; j < sp.count; ++j) { if (j) o.ch(','); o.u64(ids[sp.begin + j]); }
       }
-      put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, "\n"));
+      o.ch('\n');
     }
   } else {
-    put(snprintf(buf && cap > off ? buf + off : nullptr, buf && cap > off ? cap - off : 0, expanded ? "%s\tunclassified\t0\t0\t0\t0\t%d\t1\t\n" : "%s\tunclassified\t0\t0\t0\t0\t%d\t1\n",
-                 read_id, r->query_length));
+    o.put(read_id, idn); { static const char kUn[] = "\tunclassified\t0\t0\t0\t0\t"; o.put(kUn, sizeof(kUn) - 1); } o.i32(r->query_length); o.put("\t1", 2);
+    if (expanded) o.ch('\t');
+    o.ch('\n');
   }
-  return off;
+  if (buf && o.off < cap) buf[o.off] = '\0';
+  return o.off;
 }
 
 }  // extern "C"

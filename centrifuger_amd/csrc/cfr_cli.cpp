@@ -591,13 +591,15 @@ struct Batch {
   std::vector<cfr_match> matches;
   std::vector<cfr_span> spans;         // --expand-taxid: per match slot, its list in exp_ids
   std::vector<uint64_t> exp_ids;
-  std::string tsv;
+  std::vector<std::string> tsv_parts;  // the batch's TSV rows in order, as the formatter's workers made them (written part by part: no concatenation;
+  std::vector<size_t> part_hits;       //  the strings keep their capacity across recycling); classified reads per part
+  size_t n_parts = 0;
   bool done = false;
   const char *id(size_t i) const { return ids.data() + id_off[i]; }
   void reset() {   // keeps every buffer's capacity: batches are recycled, so steady state allocates (and page-faults) nothing
     n = 0; done = false;
     ids.clear(); id_off.clear(); qual1.clear(); qual2.clear(); q1_off.clear(); q2_off.clear(); has_qual.clear(); has_qual2.clear();
-    bases1.clear(); bases2.clear(); offs1.clear(); offs2.clear(); tsv.clear();
+    bases1.clear(); bases2.clear(); offs1.clear(); offs2.clear(); n_parts = 0;
   }
 };
 
@@ -980,7 +982,7 @@ int main(int argc, char *argv[]) {
       const size_t nchunks = cuts.size() - 1;
       std::atomic<size_t> next_chunk{0};
       size_t publish_next = 0;
-      const int workers = std::max(1, std::min<int>(opt.parse_threads > 0 ? opt.parse_threads : std::min(opt.threads, 4), (int)nchunks));
+      const int workers = std::max(1, std::min<int>(opt.parse_threads > 0 ? opt.parse_threads : std::min(opt.threads, 8), (int)nchunks));
       std::vector<std::thread> th;
       for (int w = 0; w < workers; ++w) th.emplace_back([&]() {
         std::vector<char> piece;      // the worker's private copy of its piece: pread, not page faults on a mapping every thread shares
@@ -1265,11 +1267,16 @@ int main(int argc, char *argv[]) {
       }
       const auto ts = tick();
       const int nt = (int)std::min<size_t>((size_t)format_pool.size(), std::max<size_t>(1, b->n / 4096));
-      std::vector<std::string> parts((size_t)nt);
+      if (b->tsv_parts.size() < (size_t)nt) { b->tsv_parts.resize((size_t)nt); b->part_hits.resize((size_t)nt); }
+      b->n_parts = (size_t)nt;
       format_pool.run(nt, [&](int t) {
         const size_t lo = b->n * (size_t)t / (size_t)nt, hi = b->n * (size_t)(t + 1) / (size_t)nt;
-        std::string &out = parts[(size_t)t];
-        out.reserve((hi - lo) * 96);
+        std::string &out = b->tsv_parts[(size_t)t];
+        out.clear();
+        if (out.capacity() < (hi - lo) * 64) out.reserve((hi - lo) * 96);
+        size_t hits = 0;
+        for (size_t i = lo; i < hi; ++i) hits += b->results[i].n_match > 0 ? 1 : 0;
+        b->part_hits[(size_t)t] = hits;
         char buf[8192];
         auto row = [&](size_t i, char *dst, size_t cap) {
           return expand ? cfr_format_tsv_expanded(idx, b->id(i), &b->results[i], b->matches.data(), b->spans.data(), b->exp_ids.data(), dst, cap)
@@ -1285,7 +1292,6 @@ int main(int argc, char *argv[]) {
           }
         }
       });
-      for (auto &p : parts) b->tsv += p;
       clk.add(T_FORMAT, ts);
       std::lock_guard<std::mutex> lk(mu);
       b->done = true;
@@ -1305,11 +1311,10 @@ int main(int argc, char *argv[]) {
       cv.notify_all();
     }
     const auto tw = tick();
-    fwrite(b->tsv.data(), 1, b->tsv.size(), stdout);
-    for (size_t i = 0; i < b->n; ++i) {
+    for (size_t t = 0; t < b->n_parts; ++t) { fwrite(b->tsv_parts[t].data(), 1, b->tsv_parts[t].size(), stdout); classified += b->part_hits[t]; }
+    total += b->n;
+    if (cl.fp[0] || un.fp[0]) for (size_t i = 0; i < b->n; ++i) {
       const bool hit = b->results[i].n_match > 0;
-      ++total;
-      classified += hit ? 1 : 0;
       ReadDump *dump = hit ? (cl.fp[0] ? &cl : nullptr) : (un.fp[0] ? &un : nullptr);
       if (!dump) continue;
       dump->put(0, b->id(i), b->bases1.data() + b->offs1[i], b->offs1[i + 1] - b->offs1[i],

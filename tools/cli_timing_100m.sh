@@ -13,18 +13,18 @@ n2=$(grep -c '>' $fa)
 reps=$(( M * 1000000 / n2 ))
 echo "index $idx; $fa holds $n2 reads, x $reps = $(( reps * n2 )) reads" > $out
 big=/tmp/big100m.fa
-t0=$(date +%s.%N); for i in $(seq $reps); do cat $fa; done > $big; echo "wrote $(du -h $big | cut -f1) in $(echo "$(date +%s.%N) - $t0" | bc) s" | tee -a $out
+for i in $(seq $reps); do cat $fa; done > $big; echo "wrote $(du -h $big | cut -f1)" | tee -a $out
 run() {  # label, then the command line's arguments
   local label=$1; shift
   local t0=$(date +%s.%N)
   CFR_CLI_TIMING=1 centrifuger_amd/bin/centrifuger -x $idx "$@" > /tmp/cli_100m.tsv 2> /tmp/cli_100m.err
-  local el=$(echo "$(date +%s.%N) - $t0" | bc)
+  local t1=$(date +%s.%N)
   local rows=$(( $(wc -l < /tmp/cli_100m.tsv) - 1 ))
-  echo "== $label: wall $el s, $rows rows, $(echo "$rows / $el / 1000000" | bc -l | cut -c1-6) M reads/s, md5 $(md5sum < /tmp/cli_100m.tsv | cut -c1-12)" | tee -a $out
+  echo "== $label: $(python -c "el=$t1-$t0; print('process wall %.2f s, %d rows, %.1f M reads/s' % (el, $rows, $rows/el/1e6))"), md5 $(md5sum < /tmp/cli_100m.tsv | cut -c1-12)" | tee -a $out
   grep timing /tmp/cli_100m.err | tr '\n' ' ' | tee -a $out; echo | tee -a $out
 }
 for prof in "" "--gpu-throughput"; do
-  for pt in 0 4 8 16 32; do
+  for pt in ${PTS:-0 16}; do
     run "plain FASTA -t 64 $prof --parse-threads $pt" -u $big -t 64 $prof --parse-threads $pt
   done
 done
