@@ -1102,9 +1102,9 @@ void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_
   // reads of A, C, G, T only go through the instantiation with 64-triplet tables (three waves per SIMD), the others
   // (flagged by one pass over the bases) through the one with 125; CFR_DUST_SPLIT=0: everything through the latter
   static const bool split = !(dbg_env("CFR_DUST_SPLIT") && atoi(dbg_env("CFR_DUST_SPLIT")) == 0);
-  static const int pure_per_cu = dbg_env("CFR_DUST_BLOCKS") ? std::max(1, atoi(dbg_env("CFR_DUST_BLOCKS"))) : (CFR_DUST_RINGLESS ? 9 : 6);   // resident blocks of k_dust<true>: 16.6 KB of LDS each without the ring
+  static const int pure_per_cu = dbg_env("CFR_DUST_BLOCKS") ? std::max(1, atoi(dbg_env("CFR_DUST_BLOCKS"))) : (CFR_DUST_RINGLESS ? 9 : 6) * (128 / kDustBlock) + (kDustBlock == 64 && !CFR_DUST_RINGLESS ? 1 : 0);   // resident blocks of k_dust<true>: 16.6 KB of LDS each without the ring
   const unsigned blocks_pure = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * pure_per_cu));
-  const unsigned blocks_any = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * 4));
+  const unsigned blocks_any = std::min<unsigned>(grid_for(n, kDustBlock), (unsigned)(num_cus_ * (kDustBlock == 64 ? 7 : 4)));
   uint32_t *pool = (uint32_t *)scratch(st == stream_ ? S_DUSTPOOL : S_DUSTPOOL2,
                                        ((size_t)(blocks_pure + blocks_any) * kDustBlock * 64 + kDustPoolHead) * sizeof(uint32_t));   // one table per stream
   HIP_CHECK(hipMemsetAsync(pool, 0, kDustPoolHead * sizeof(uint32_t), st));      // the counters the lanes draw reads from
