@@ -100,6 +100,8 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   for (auto &e : copy_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto &e : h2d_done_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&h2d_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&search2_stream_, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&prep_done_, hipEventDisableTiming));
   HIP_CHECK(hipStreamCreateWithFlags(&dust_stream_, hipStreamNonBlocking));
   for (auto &e : copied_) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   {
@@ -699,6 +701,8 @@ void DeviceIndex::release() {            // idempotent: also the clean-up of a c
   for (auto &e : search_done_) drop_event(e);
   auto drop_stream = [](hipStream_t &s) { if (s) (void)hipStreamDestroy(s); s = nullptr; };
   drop_stream(tail_stream_);
+  drop_stream(search2_stream_);
+  if (prep_done_) { (void)hipEventDestroy(prep_done_); prep_done_ = nullptr; }
   drop_stream(h2d_stream_);
   drop_stream(dust_stream_);
   drop_stream(copy_stream_);
@@ -828,6 +832,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
                                                   uint64_t total1, uint64_t total2, int par, bool row_space_only) {
   const bool paired = d_b2 != nullptr;
   const int cpr = paired ? 4 : 2;
+  hipStream_t sst = search_stream_ ? search_stream_ : stream_;      // (the stream this search is enqueued on: see two_search in classify_device)
   const size_t nchains = n * (size_t)cpr;
   // capacity bound without a host round trip: sum over chains of (len/(mhl+1) + 1)
   const uint64_t mhl1 = (uint64_t)view_.min_hit_len + 1;
@@ -844,19 +849,19 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
   // text-space hits (k_search_chains_v2, virt_text_pos): searches that finish on the text keep virtual rows
   const bool text_hits = !search_v1_ && !row_space_only && have_sa() && view_.steps.pos && view_.text2;
 
-  HIP_CHECK(hipEventRecord(ev_[0], stream_));
+  HIP_CHECK(hipEventRecord(ev_[0], sst));
   if (pre_hit_off_) {                    // the offsets exist (one pass over the whole batch): the sub-batch's lists start at pre_hit_base_
     hit_off = const_cast<uint64_t *>(pre_hit_off_);
     raw = reinterpret_cast<cfr_hit *>(reinterpret_cast<uintptr_t>(raw) - (uintptr_t)pre_hit_base_ * sizeof(cfr_hit));
   } else {
-    HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, stream_));
-    k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap);
-    exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, stream_);
+    HIP_CHECK(hipMemsetAsync(cap + n, 0, 8, sst));
+    k_caps<<<grid_for(n), kBlock, 0, sst>>>(view_, d_o1, d_o2, n, cap);
+    exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, sst);
   }
-  HIP_CHECK(hipEventRecord(ev_[1], stream_));
+  HIP_CHECK(hipEventRecord(ev_[1], sst));
   if (search_v1_) {
-    if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
-    else k_search_chains<2><<<grid_for(nchains), kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
+    if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, sst>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
+    else k_search_chains<2><<<grid_for(nchains), kBlock, 0, sst>>>(view_, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt);
   } else {
     // persistent grid: every lane walks chains gid, gid + T, ... (T = resident lanes), see k_search_chains_v2
     // resident blocks only: a block that had to wait for a slot would start its share of the chains late
@@ -894,7 +899,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     // profiles/r5_ab_post_and_tiles.txt.  CFR_SEARCH_DYN=0 / 1 / 2: static / per-lane draws / wave tiles.
     int dyn_mode = -1;
     const bool short_reads = (total1 + total2) / std::max<size_t>(1, nchains) < 500;
-    if (!dyn && short_reads && nchains > 4ull * blocks * kBlock && nchains < 0xfff00000ull && (paired || heavy_frac_ > 0.2)) { dyn = true; dyn_mode = 2; }
+    if (!dyn && short_reads && nchains > 4ull * blocks * kBlock && nchains < 0xfff00000ull && (paired || heavy_frac_ > 0.2 || two_search_now_)) { dyn = true; dyn_mode = 2; }
     if (const char *e = dbg_env("CFR_SEARCH_DYN")) { dyn_mode = atoi(e); dyn = dyn_mode != 0; }
     // short reads handed out dynamically (so that the post stage of the previous sub-batch can run beside this search: a block that
     // starts late then simply takes fewer chains): eight chains per draw; long reads: one
@@ -903,21 +908,21 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     if (dyn && dyn_mode == 2 && nchains < 0xfff00000ull) dyn_chunk = dbg_env("CFR_SEARCH_TILE") ? (uint32_t)std::max(64, atoi(dbg_env("CFR_SEARCH_TILE"))) : 64u;
     unsigned long long *d_ctr = nullptr;
     if (dyn) {
-      d_ctr = (unsigned long long *)scratch(S_P5, 16 * 8) + 15;
-      HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, stream_));
+      d_ctr = (unsigned long long *)scratch(S_P5, 16 * 8) + (par ? 14 : 15);          // (a counter per set of outputs: two searches may be in flight)
+      HIP_CHECK(hipMemsetAsync(d_ctr, 0, 8, sst));
     }
     const uint64_t *p2 = paired ? packed2_ : nullptr, *o2 = paired ? d_o2 : nullptr;
     const uint64_t nb2 = paired ? nblk2_ : 0;
 #define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
-    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, stream_>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
+    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
     if (dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
-      HIP_CHECK(hipMemsetAsync(d_prof, 0, 15 * 8, stream_));
+      HIP_CHECK(hipMemsetAsync(d_prof, 0, 15 * 8, sst));
       if (wide) { if (dyn) CFR_LAUNCH_SEARCH(2, true, true, true, d_prof); else CFR_LAUNCH_SEARCH(2, true, true, false, d_prof); }
       else { if (dyn) CFR_LAUNCH_SEARCH(2, true, false, true, d_prof); else CFR_LAUNCH_SEARCH(2, true, false, false, d_prof); }
-      HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 15 * 8, hipMemcpyDeviceToHost, stream_));
-      HIP_CHECK(hipStreamSynchronize(stream_));
+      HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 15 * 8, hipMemcpyDeviceToHost, sst));
+      HIP_CHECK(hipStreamSynchronize(sst));
       static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "text_hits", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
@@ -932,7 +937,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
 #undef CFR_LAUNCH_SEARCH
   }
   HIP_CHECK(hipGetLastError());
-  HIP_CHECK(hipEventRecord(ev_[2], stream_));
+  HIP_CHECK(hipEventRecord(ev_[2], sst));
   return SearchBuf{hit_off, raw, chain_cnt, cap_total};
 }
 
@@ -1465,6 +1470,13 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // waves.  So it is the default whenever a batch has more than one sub-batch (CFR_TAIL_STREAM=0/1 forces it).
   const bool tail_overlap = tail_overlap_mode_ >= 0 ? tail_overlap_mode_ != 0 : true;
   overlap_now_ = tail_overlap && one_launch && nsub > 1;
+  // (only where the sub-batches' inputs are ready before the first search - resident reads, offsets in one pass - and chains go by wave tiles)
+  // Measured (profiles/r5_ab_post_and_tiles.txt, section 7): no gain - cfg2 12.0 against 11.9 ms, pairs / 20 / 200 strains unchanged - so it is
+  // OFF unless CFR_SEARCH_TWO=1 asks for it: the launches of a step do not lose their time in the drain of the one before.
+  bool two_search = false;
+  if (const char *e = dbg_env("CFR_SEARCH_TWO")) two_search = (overlap_now_ && caps_once && !pack_late && !dust_pieces && !search_v1_ && !view_.prot.enabled) && atoi(e) != 0;
+  two_search_now_ = two_search;
+  bool prep_waited = false;
   if (src && !one_launch) throw HipError{"streamed host inputs need the one-launch post stage", -4};
   bring_piece(0);
 
@@ -1534,15 +1546,22 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         // fabric's request rate.  Two sets of search outputs: search k + 2 waits for the post stage of k.
         const int par = tail_overlap ? (int)(k & 1) : 0;
         hipStream_t ts = tail_overlap ? tail_stream_ : stream_;
-        if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(stream_, tail_done_[par], 0));
+        // two_search (round 5): the searches of odd sub-batches on a second stream, so that search k + 1 moves into the CUs as the blocks of
+        // search k finish (a persistent grid ends with its slowest block; chains are handed out by wave tiles, so a block that starts late
+        // simply takes fewer).  Everything else of a sub-batch follows its search as before.
+        hipStream_t ss = two_search && par ? search2_stream_ : stream_;
+        search_stream_ = ss;
+        if (two_search && par && !prep_waited) { HIP_CHECK(hipEventRecord(prep_done_, stream_)); HIP_CHECK(hipStreamWaitEvent(search2_stream_, prep_done_, 0)); prep_waited = true; }
+        if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(ss, tail_done_[par], 0));
         if (pack_rest_pending && k >= 1) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[0], 0)); pack_rest_pending = false; }
         pre_hit_off_ = hit_all ? hit_all + lo : nullptr;
         pre_hit_base_ = hit_all ? hbase[k] : 0;
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], par);
         pre_hit_off_ = nullptr;
-        for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], stream_));
+        search_stream_ = nullptr;
+        for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], ss));
         if (tail_overlap) {
-          HIP_CHECK(hipEventRecord(search_done_[par], stream_));
+          HIP_CHECK(hipEventRecord(search_done_[par], ss));
           HIP_CHECK(hipStreamWaitEvent(ts, search_done_[par], 0));
         }
         unsigned long long *ctl = (unsigned long long *)scratch((k & 1) ? S_POOLCTL1 : S_POOLCTL, 64);    // pool cursor, overflow flag, heavy reads (two tiers), slow reads
@@ -1620,6 +1639,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         if (attempt == 0 && k + 1 < nsub) bring_piece(k + 1);          // the host copies the next piece while this one computes
       }
       HIP_CHECK(hipStreamSynchronize(stream_));
+      if (two_search) HIP_CHECK(hipStreamSynchronize(search2_stream_));
       HIP_CHECK(hipStreamSynchronize(tail_stream_));
       HIP_CHECK(hipStreamSynchronize(copy_stream_));
       if (attempt == 0) for (size_t k = 0; k < nsub; ++k) { ev_ = evs_[k]; finish_stats(true); }

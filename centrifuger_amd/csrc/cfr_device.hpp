@@ -246,6 +246,9 @@ class DeviceIndex {
   hipEvent_t evs_[kMaxSub][9] = {};      // per sub-batch: 0-2 around the search, 8 and 3-7 around the stages behind it
   hipEvent_t *ev_ = nullptr;
   hipStream_t copy_stream_ = nullptr, h2d_stream_ = nullptr, tail_stream_ = nullptr, dust_stream_ = nullptr;
+  hipStream_t search2_stream_ = nullptr, search_stream_ = nullptr;   // the second search stream; the stream launch_search enqueues on (nullptr: stream_)
+  hipEvent_t prep_done_ = nullptr;
+  bool two_search_now_ = false;
   hipEvent_t search_done_[2] = {};
   int tail_overlap_mode_ = -1;           // the post stage of a sub-batch beside the search of the next one: -1 = by heavy_frac_, 0 / 1
   bool overlap_now_ = false, blocks_forced_ = false;   // this call runs the post stage beside the next search; CFR_BLOCKS_PER_CU was given

@@ -476,7 +476,7 @@ def test_k_above_64_lists_every_strain_like_the_reference(tmp_path):
     import torch
     from centrifuger_amd import indexbuild
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    g = synth.make_genomes(2, 90, 20_000, seed=3301, divergence_step=0.0002)
+    g = synth.make_genomes(2, 90, 20_000, seed=3301, divergence_step=0.00002)
     prefix = str(tmp_path / "idx")
     indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
     rs = synth.make_reads(g, 3000, 150, seed=3302, sub_rate=0.003, n_rate=0.0005)

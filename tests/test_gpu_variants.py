@@ -64,6 +64,10 @@ VARIANTS = {
     "search_wave_tiles_of_128_small_subbatches": {"CFR_SEARCH_DYN": "2", "CFR_SEARCH_TILE": "128", "CFR_SUBBATCH": "61"},
     "search_static_hand_out": {"CFR_SEARCH_DYN": "0"},
     "search_lane_draws": {"CFR_SEARCH_DYN": "1"},
+    # the searches of odd sub-batches on a second stream (measured: no gain; kept as a switch)
+    "two_search_streams": {"CFR_SEARCH_TWO": "1", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0"},
+    # K-mer entries without the text position of their one row (the form before round 5)
+    "ftabx_without_text_positions": {"CFR_FTABX_TEXTPOS": "0"},
 }
 
 
