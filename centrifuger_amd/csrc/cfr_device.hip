@@ -986,17 +986,24 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search_protein(const uint8_t *d_b1, c
     }
     sm_blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * occ));
   }
+  // chains by wave tiles (round 5; CFR_PROT_DYN=0: chain + T)
+  unsigned long long *prot_ctr = nullptr;
+  static const bool prot_dyn = !(dbg_env("CFR_PROT_DYN") && atoi(dbg_env("CFR_PROT_DYN")) == 0);
+  if (sm && prot_dyn) {
+    prot_ctr = (unsigned long long *)scratch(S_P4, 16 * 8);
+    HIP_CHECK(hipMemsetAsync(prot_ctr, 0, 8, stream_));
+  }
   if (paired) {
     k_translate_prot<2><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, d_b2, d_o2, n, codes1, codes2, read0);
-    if (sm && sm_minb == 6) k_search_prot_sm<2, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
-    else if (sm) k_search_prot_sm<2, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
+    if (sm && sm_minb == 6) k_search_prot_sm<2, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0, prot_ctr, 64u);
+    else if (sm) k_search_prot_sm<2, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0, prot_ctr, 64u);
     else if (minb == 8) k_search_prot<2, 8><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
     else if (minb == 6) k_search_prot<2, 6><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
     else k_search_prot<2, 1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt, codes1, codes2, read0);
   } else {
     k_translate_prot<1><<<tr_grid, kBlock, 0, stream_>>>(view_, d_b1, d_o1, nullptr, nullptr, n, codes1, nullptr, read0);
-    if (sm && sm_minb == 6) k_search_prot_sm<1, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
-    else if (sm) k_search_prot_sm<1, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
+    if (sm && sm_minb == 6) k_search_prot_sm<1, 6><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0, prot_ctr, 64u);
+    else if (sm) k_search_prot_sm<1, 1><<<sm_blocks, kBlock, 0, stream_>>>(sview, d_o1, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0, prot_ctr, 64u);
     else if (minb == 8) k_search_prot<1, 8><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
     else if (minb == 6) k_search_prot<1, 6><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);
     else k_search_prot<1, 1><<<grid_for(nchains), kBlock, 0, stream_>>>(sview, d_b1, d_o1, nullptr, nullptr, n, hit_off, raw, chain_cnt, codes1, nullptr, read0);

@@ -35,8 +35,8 @@ BUDGET = {
     # translated search: the default instantiation has none; the 80-register one (6 blocks per CU) spills two loop invariants
     "k_search_prot_sm<1, 1>": (96, 0),
     "k_search_prot_sm<2, 1>": (96, 0),
-    "k_search_prot_sm<1, 6>": (80, 8),
-    "k_search_prot_sm<2, 6>": (80, 16),
+    "k_search_prot_sm<1, 6>": (80, 20),
+    "k_search_prot_sm<2, 6>": (80, 32),
     # SDUST: lane state machines, window state in LDS
     "k_dust<true>": (96, 0),
     "k_dust<false>": (96, 0),
