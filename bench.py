@@ -1535,7 +1535,6 @@ def main():
             # rows are the reference's rows of the sample, repeated); a run of a few seconds in which the index load no longer dominates
             if world == 1 and args.mode == "se" and not paired and not args.sub_result and len(files) == 2 and not args.no_extra_configs:
                 try:
-                    import hashlib
                     reps = max(1, 100_000_000 // nb)
                     big = os.path.join(cache, "e2e_100m.fa")
                     with open(big, "wb") as fo:
