@@ -274,12 +274,18 @@ def live_pmc(args, cache, gpu=0):
     vals, dur = {}, None
     work = tempfile.mkdtemp(prefix="cfr_pmc_", dir="/tmp")
     try:
-        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"])):
+        # (third pass, round 5: the kernel's instruction stream - the search is bound by it as much as by its gathers)
+        for gi, group in enumerate((["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "FETCH_SIZE"], ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],
+                                    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE"])):
+            if gi == 2 and getattr(args, "sub_result", False):
+                break                  # (the main line only: a pass over a 40 Gbp sub-result costs a minute and a half)
             d = os.path.join(work, f"pass{gi}")
             r = subprocess.run([rocprof, "--pmc"] + group + ["--kernel-trace", "--output-format", "csv", "--kernel-include-regex", "k_search_chains_v2",
                                 "-d", d, "--"] + inner, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
             if r.returncode != 0:
                 log("live PMC pass failed:", r.stderr.decode()[-400:])
+                if gi == 2:
+                    break              # (the traffic counters are in: the line goes out without the instruction-stream object)
                 return None
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -298,6 +304,7 @@ def live_pmc(args, cache, gpu=0):
                 "reads": n_inner, "rdreq": vals["TCC_EA0_RDREQ_sum"], "rdreq_32b": vals.get("TCC_EA0_RDREQ_32B_sum", 0.0),
                 "fetch_size_kib": vals.get("FETCH_SIZE", 0.0), "write_size_kib": vals["WRITE_SIZE"], "kernel_ms_profiled": dur, "prof": prof,
                 "l2_hit": (vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"])) if vals.get("TCC_HIT_sum") is not None and (vals.get("TCC_HIT_sum", 0) + vals.get("TCC_MISS_sum", 0)) > 0 else None,
+                "sq": {k_: vals[k_] for k_ in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "GRBM_GUI_ACTIVE") if k_ in vals},
                 "kernel_source_sha": kernel_source_sha()}
     except Exception as e:
         log("live PMC unavailable:", repr(e))
@@ -495,6 +502,31 @@ def post_stage_roofline(pm, reads, tail_ms, search_requests_per_read=None, hits_
     return out
 
 
+def instruction_stream(pmc):
+    """The search kernel's own instruction stream from the SQ pass of live_pmc (one launch alone on the chip): wave64 vector instructions
+    per read and per lane iteration, the VALU issue rate they amount to (a wave64 VALU instruction occupies its SIMD-32 for 2 cycles:
+    peak = 1024 SIMDs x clock / 2), and where the waves' cycles go.  SQ_*_CYCLES are quad-cycles."""
+    sq = (pmc or {}).get("sq") or {}
+    ms = (pmc or {}).get("kernel_ms_profiled")
+    if "SQ_INSTS_VALU" not in sq or not ms:
+        return None
+    n = pmc["reads"]
+    clock = (sq["GRBM_GUI_ACTIVE"] / 8.0 / (ms / 1e3)) if sq.get("GRBM_GUI_ACTIVE") else 2.4e9
+    iters = (pmc.get("prof") or {}).get("lane_iterations")
+    wc = sq.get("SQ_WAVE_CYCLES")
+    return {"valu_wave_instructions_per_read": sq["SQ_INSTS_VALU"] / n, "salu_wave_instructions_per_read": (sq["SQ_INSTS_SALU"] / n) if sq.get("SQ_INSTS_SALU") is not None else None,
+            "vmem_read_wave_instructions_per_read": (sq["SQ_INSTS_VMEM_RD"] / n) if sq.get("SQ_INSTS_VMEM_RD") is not None else None,
+            "valu_issue_frac": sq["SQ_INSTS_VALU"] / (ms / 1e3) / (1024.0 * clock / 2.0), "clock_GHz": clock / 1e9,
+            "valu_wave_instructions_per_wave_iteration": (sq["SQ_INSTS_VALU"] * 64.0 / (n * iters)) if iters else None,
+            "waves_per_simd": (wc * 4.0 / ((ms / 1e3) * clock * 1024.0)) if wc else None,
+            "wave_cycles_waiting": (sq["SQ_WAIT_ANY"] / wc) if wc and sq.get("SQ_WAIT_ANY") is not None else None,
+            "wave_cycles_executing": (sq["SQ_ACTIVE_INST_ANY"] / wc) if wc and sq.get("SQ_ACTIVE_INST_ANY") is not None else None,
+            "note": "lanes of a wave are in different states of the search, so a wave runs nearly every branch of the loop in every iteration: "
+                    "valu_wave_instructions_per_wave_iteration is taken as if the lanes' iterations were spread evenly over full waves.  Round 5 cut "
+                    "the static instruction count (-18 %), the lane iterations (-12 %) and the fabric requests (-6 %; block loads -33 % with a dense "
+                    "read form) of this kernel in turn: none of it shortened the kernel on one box (profiles/r5r_ab_libs.txt, r5l_ab_dense.txt)"}
+
+
 def mini_roofline(pmc, reads, search_ms):
     """roofline object of a sub-result (same counter arithmetic as the main line's: 128-byte requests, WRITE_SIZE, 8 TB/s)"""
     if not pmc:
@@ -514,6 +546,7 @@ def mini_roofline(pmc, reads, search_ms):
             "traffic": traffic, "fabric_read_requests_per_read": pmc["rdreq"] / pmc["reads"], "l2_hit": pmc.get("l2_hit"),
             "gather": {"requests_per_s": req_s, "ceiling_per_s": 48e9, "frac": req_s / 48e9},
             "gather_frac_of_48G_requests_per_s": req_s / 48e9, "iteration_mix_per_read": pmc.get("prof"), "traffic_source": pmc["source"],
+            "instruction_stream": instruction_stream(pmc),
             "yardsticks": "frac = frac_useful_bytes (bytes of the fetched lines the kernel consumes / kernel time / 8 TB/s); frac_counter_traffic = fabric bytes by PMC / kernel time / 8 TB/s"}
 
 
@@ -1305,6 +1338,7 @@ def main():
               roof["frac_kernel_alone"] = traffic / (alone_ms / 1e3) / 1e9 / HBM_PEAK_GBS
               roof["kernel_ms_alone"] = alone_ms
           roof["l2_hit"] = pmc.get("l2_hit")
+          roof["instruction_stream"] = instruction_stream(pmc)
           if pmc.get("prof"):
               pr = pmc["prof"]
               useful = useful_bytes_per_read(pr, c.get("hits", 0) / ns)

@@ -38,7 +38,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_SLOW, S_SLOW1, S_DENSE1, S_DENSE2, S_NSMAP1, S_NSMAP2, S_PRM, S_PRM1, S_PRMALL, S_PRMBAD, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_SLOW, S_SLOW1, S_COUNT
 };
 
 }  // namespace
@@ -858,17 +858,6 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     k_caps<<<grid_for(n), kBlock, 0, sst>>>(view_, d_o1, d_o2, n, cap);
     exclusive_scan(tmp, tmp_bytes, cap, hit_off, n, sst);
   }
-  // the chains' parameter records (k_chain_params): made here for this sub-batch unless classify_device made them for the whole batch
-  const ulonglong2 *prm = nullptr;
-  if (!search_v1_ && prm_bad_ != nullptr) {
-    if (pre_prm_) prm = pre_prm_;
-    else {
-      ulonglong2 *q = (ulonglong2 *)scratch(par ? S_PRM1 : S_PRM, n * (paired ? 4 : 2) * sizeof(ulonglong2));
-      k_chain_params<<<grid_for(n), kBlock, 0, sst>>>(d_o1, d_o2, hit_off, nsmap1_, paired ? nsmap2_ : nullptr, n, q, prm_bad_, prm_chars_ ? packed1_ : nullptr,
-                                                      prm_chars_ && paired ? packed2_ : nullptr);
-      prm = q;
-    }
-  }
   HIP_CHECK(hipEventRecord(ev_[1], sst));
   if (search_v1_) {
     if (paired) k_search_chains<4><<<grid_for(nchains), kBlock, 0, sst>>>(view_, d_b1, d_o1, d_b2, d_o2, n, hit_off, raw, chain_cnt);
@@ -936,8 +925,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const uint64_t *p2 = paired ? packed2_ : nullptr, *o2 = paired ? d_o2 : nullptr;
     const uint64_t nb2 = paired ? nblk2_ : 0;
 #define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
-    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk, \
-                                                                             dense1_, paired ? dense2_ : nullptr, prm, prm_bad_)
+    k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
     if (dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
@@ -1186,47 +1174,20 @@ void DeviceIndex::dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n)
 }
 
 // 2-bit packed form of the read buffers for k_search_chains_v2 (once per batch call, before the sub-batches)
-// Round 5: beside it the dense form (codes only, 64 characters per 16 bytes) with the map of superblocks that hold a non-symbol, and the
-// flag the parameter records raise when a value does not fit them (k_pack_reads / k_chain_params; CFR_DENSE=0, CFR_PRM=0: without).
-// allow_dense = false: a caller whose blocks do not come from k_pack_reads in time for the records (packed host blocks copied in place,
-// the late-packing test hooks).
-void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now, bool allow_dense) {
-  // Measured (profiles/r5l_ab_dense.txt, r5m_ab_dense.txt): the dense form takes the search's block loads from 11.6 to 7.8 per read and makes
-  // the kernel SLOWER (cfg2 9.1 -> 9.7 ms, pairs 16.5 -> 17.2) - the kernel is bound by its instruction stream, not by its requests, and the
-  // second queue path adds instructions to every iteration.  Compiled out unless the library is built with -DCFR_DENSE_FORM=1.
-  static const bool dense_on = kDenseForm && !(dbg_env("CFR_DENSE") && atoi(dbg_env("CFR_DENSE")) == 0);
-  static const bool prm_on = !(dbg_env("CFR_PRM") && atoi(dbg_env("CFR_PRM")) == 0);
-  // CFR_PRM_CHARS=0: records without the chains' first characters.  allow_dense = false also means the blocks may not be there when the
-  // records are made (packed host blocks copied in place piece by piece): no characters then
-  prm_chars_ = allow_dense && !(dbg_env("CFR_PRM_CHARS") && atoi(dbg_env("CFR_PRM_CHARS")) == 0);
-  const bool want_dense = dense_on && prm_on && allow_dense;
+void DeviceIndex::pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now) {
   // 4 zero blocks ("not a symbol") in front of and behind the packed form: the search kernel fetches block pairs
-  auto pack_one = [&](size_t slot, size_t dslot, size_t nslot, const uint8_t *d_b, uint64_t total, uint64_t &nblk, uint32_t *&dense, uint32_t *&nsmap) -> uint64_t * {
+  auto pack_one = [&](size_t slot, const uint8_t *d_b, uint64_t total, uint64_t &nblk) -> uint64_t * {
     nblk = (total + 15) / 16;
     uint64_t *base = (uint64_t *)scratch(slot, (nblk + 8) * 8);
     HIP_CHECK(hipMemsetAsync(base, 0, 4 * 8, stream_));
     HIP_CHECK(hipMemsetAsync(base + 4 + nblk, 0, 4 * 8, stream_));
-    dense = nullptr; nsmap = nullptr;
-    if (want_dense) {
-      dense = (uint32_t *)scratch(dslot, (((nblk + 3) & ~3ull) + 12) * 4);
-      const size_t map_bytes = ((nblk >> 7) + 2) * 4;
-      nsmap = (uint32_t *)scratch(nslot, map_bytes);
-      HIP_CHECK(hipMemsetAsync(nsmap, 0, map_bytes, stream_));
-      HIP_CHECK(hipMemsetAsync(dense + (nblk & ~3ull), 0, 8 * 4, stream_));      // (the blocks behind the last one of the last superblock)
-    }
-    if (nblk && pack_now) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(d_b, total, nblk, base + 4, dense, nsmap, 0);
+    if (nblk && pack_now) k_pack_reads<<<grid_for(nblk), kBlock, 0, stream_>>>(d_b, total, nblk, base + 4);
     return base + 4;
   };
-  packed1_ = pack_one(S_PACK1, S_DENSE1, S_NSMAP1, d_b1, total1, nblk1_, dense1_, nsmap1_);
+  packed1_ = pack_one(S_PACK1, d_b1, total1, nblk1_);
   nblk2_ = 0;
-  packed2_ = nullptr; dense2_ = nullptr; nsmap2_ = nullptr;
-  if (d_b2) packed2_ = pack_one(S_PACK2, S_DENSE2, S_NSMAP2, d_b2, total2, nblk2_, dense2_, nsmap2_);
-  prm_bad_ = nullptr;
-  if (prm_on) {
-    prm_bad_ = (uint32_t *)scratch(S_PRMBAD, 64);
-    HIP_CHECK(hipMemsetAsync(prm_bad_, 0, 4, stream_));
-  }
-  pre_prm_ = nullptr;
+  packed2_ = nullptr;
+  if (d_b2) packed2_ = pack_one(S_PACK2, d_b2, total2, nblk2_);
   HIP_CHECK(hipGetLastError());
 }
 
@@ -1388,7 +1349,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // the 0.4 ms of packing it takes out of the front come back as a slower first search; everything up front on the main stream stays
   static const bool pack_split_on = dbg_env("CFR_PACK_SPLIT") && atoi(dbg_env("CFR_PACK_SPLIT")) != 0;
   const bool pack_late = (pack_pieces_on || pack_split_on) && !by_piece && !search_v1_;
-  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece && !pack_late, /*allow_dense=*/!pack_late && !(src && src->p1 && !src->stage1));
+  if (!search_v1_) pack_inputs(d_b1, total1, d_b2, total2, /*pack_now=*/!by_piece && !pack_late);
   size_t sb = 0;
   const auto pieces = cut_pieces(n, stride > 0, sb, total1 + total2);
   const size_t nsub = pieces.size();
@@ -1401,8 +1362,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   static const bool caps_once_on = !(dbg_env("CFR_CAPS_ONCE") && atoi(dbg_env("CFR_CAPS_ONCE")) == 0);
   const bool caps_once = caps_once_on && !src && !dust_pieces && nsub > 1 && stride > 0 && one_launch_ready() && !search_v1_;
   uint64_t *hit_all = nullptr;
-  ulonglong2 *prm_all = nullptr;
-  bool prm_rest_pending = false;            // the records of sub-batches 1.. are being made on the upload stream (event copied_[2])
   std::vector<uint64_t> hbase(nsub + 1, 0);
   if (caps_once) {
     uint64_t *cap_all = (uint64_t *)scratch(S_CAPALL, (n + 1) * 8);
@@ -1412,23 +1371,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     HIP_CHECK(hipMemsetAsync(cap_all + n, 0, 8, stream_));
     k_caps<<<grid_for(n), kBlock, 0, stream_>>>(view_, d_o1, d_o2, n, cap_all);
     exclusive_scan(tmp, tb, cap_all, hit_all, n, stream_);
-    if (prm_bad_ != nullptr && !pack_late) {       // the chains' parameter records of the whole batch (the blocks are packed: the non-symbol maps are complete)
-      // the first sub-batch's records in front of its search, the others' on the (idle) upload stream beside it: a streaming kernel under a
-      // search that is bound by its instruction stream (0.25 ms of a step when all of them ran up front)
-      prm_all = (ulonglong2 *)scratch(S_PRMALL, n * (d_b2 ? 4 : 2) * sizeof(ulonglong2));
-      const size_t per = d_b2 ? 4 : 2, n0 = pieces[0].second;
-      k_chain_params<<<grid_for(n0), kBlock, 0, stream_>>>(d_o1, d_b2 ? d_o2 : nullptr, hit_all, nsmap1_, d_b2 ? nsmap2_ : nullptr, n0, prm_all, prm_bad_,
-                                                           prm_chars_ ? packed1_ : nullptr, prm_chars_ && d_b2 ? packed2_ : nullptr);
-      if (n > n0) {
-        HIP_CHECK(hipEventRecord(copied_[1], stream_));                  // (offsets scanned, blocks packed, prm_bad_ cleared)
-        HIP_CHECK(hipStreamWaitEvent(h2d_stream_, copied_[1], 0));
-        k_chain_params<<<grid_for(n - n0), kBlock, 0, h2d_stream_>>>(d_o1 + n0, d_b2 ? d_o2 + n0 : nullptr, hit_all + n0, nsmap1_, d_b2 ? nsmap2_ : nullptr, n - n0,
-                                                                     prm_all + per * n0, prm_bad_, prm_chars_ ? packed1_ : nullptr, prm_chars_ && d_b2 ? packed2_ : nullptr);
-        HIP_CHECK(hipEventRecord(copied_[2], h2d_stream_));
-        prm_rest_pending = true;
-      }
-      HIP_CHECK(hipGetLastError());
-    }
   }
   if (nsub > 1 || by_piece) {
     if (src) {
@@ -1459,7 +1401,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   bool pack_rest_pending = false;
   if (pack_late && !pack_late_now) {
     // blocks [from, to) of a buffer on stream st
-    auto part = [&](const uint8_t *db, uint64_t total, uint64_t *packed, uint64_t from, uint64_t to, hipStream_t st) {      // (no dense form here: pack_inputs was told)
+    auto part = [&](const uint8_t *db, uint64_t total, uint64_t *packed, uint64_t from, uint64_t to, hipStream_t st) {
       if (to > from) k_pack_reads<<<grid_for(to - from), kBlock, 0, st>>>(db + (from << 4), total - (from << 4), to - from, packed + from);
     };
     if (nsub > 1) {
@@ -1529,13 +1471,12 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
     if (!by_piece && !pack_late_now) return;
     if (by_piece) HIP_CHECK(hipStreamWaitEvent(stream_, h2d_done_[k], 0));
     if (src && src->p1 && !src->stage1) return;       // the caller's packed blocks are in place (with SDUST they went to the staging copy and the masked characters are packed here)
-    auto one = [&](uint64_t from, uint64_t to, const uint8_t *db, uint64_t total, uint64_t *packed, uint32_t *dense, uint32_t *nsmap) {
+    auto one = [&](uint64_t from, uint64_t to, const uint8_t *db, uint64_t total, uint64_t *packed) {
       const uint64_t b0 = from >> 4, b1x = (to + 15) >> 4;                // the blocks the piece touches (a block shared with the
-      if (b1x > b0) k_pack_reads<<<grid_for(b1x - b0), kBlock, 0, stream_>>>(db + (b0 << 4), total - (b0 << 4), b1x - b0, packed + b0,    // next piece is packed again there)
-                                                                             dense ? dense + b0 : nullptr, nsmap, b0);
+      if (b1x > b0) k_pack_reads<<<grid_for(b1x - b0), kBlock, 0, stream_>>>(db + (b0 << 4), total - (b0 << 4), b1x - b0, packed + b0);   // next piece is packed again there)
     };
-    one(b1[k], b1[k + 1], d_b1, total1, packed1_, dense1_, nsmap1_);
-    if (paired) one(b2[k], b2[k + 1], d_b2, total2, packed2_, dense2_, nsmap2_);
+    one(b1[k], b1[k + 1], d_b1, total1, packed1_);
+    if (paired) one(b2[k], b2[k + 1], d_b2, total2, packed2_);
     HIP_CHECK(hipGetLastError());
   };
   // the post stage beside the next sub-batch's search: pays when the post stage is long (reads over families of strains:
@@ -1631,13 +1572,10 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
         if (two_search && par && !prep_waited) { HIP_CHECK(hipEventRecord(prep_done_, stream_)); HIP_CHECK(hipStreamWaitEvent(search2_stream_, prep_done_, 0)); prep_waited = true; }
         if (tail_overlap) HIP_CHECK(hipStreamWaitEvent(ss, tail_done_[par], 0));
         if (pack_rest_pending && k >= 1) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[0], 0)); pack_rest_pending = false; }
-        if (prm_rest_pending && k >= 1) { HIP_CHECK(hipStreamWaitEvent(ss, copied_[2], 0)); if (!two_search || k >= 2) prm_rest_pending = false; }
         pre_hit_off_ = hit_all ? hit_all + lo : nullptr;
         pre_hit_base_ = hit_all ? hbase[k] : 0;
-        pre_prm_ = prm_all ? prm_all + (paired ? 4 : 2) * lo : nullptr;
         const SearchBuf sbuf = launch_search(d_b1, d_o1 + lo, d_b2, paired ? d_o2 + lo : nullptr, cnt, pt1[k], pt2[k], par);
         pre_hit_off_ = nullptr;
-        pre_prm_ = nullptr;
         search_stream_ = nullptr;
         for (int e : {8, 3, 4, 5, 6}) HIP_CHECK(hipEventRecord(ev_[e], ss));
         if (tail_overlap) {
@@ -1745,7 +1683,6 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
 
   // ---- multi-kernel form: search, adjust/select, (compact, rows, locate,) tail; one or two 8-byte host syncs per piece
   if (pack_rest_pending) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[0], 0)); pack_rest_pending = false; }
-  if (prm_rest_pending) { HIP_CHECK(hipStreamWaitEvent(stream_, copied_[2], 0)); prm_rest_pending = false; }
   for (size_t k : todo) {
     const size_t lo = pieces[k].first, cnt = pieces[k].second;
     ev_ = evs_[k];

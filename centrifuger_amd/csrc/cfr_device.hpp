@@ -223,7 +223,7 @@ class DeviceIndex {
   void *scratch(size_t slot, size_t bytes);
   void *pinned(size_t bytes);
   void finish_stats(bool want_rows);
-  void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true, bool allow_dense = true);
+  void pack_inputs(const uint8_t *d_b1, uint64_t total1, const uint8_t *d_b2, uint64_t total2, bool pack_now = true);
   void expand_begin();                   // before the kernels of a classify call: pool in place, cursor zero, both views know it
   bool expand_end();                     // behind them: false = the pool was too small (it has been enlarged: run the call again)
   uint64_t exp_cap_ = 0;
@@ -263,11 +263,6 @@ class DeviceIndex {
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
-  uint32_t *dense1_ = nullptr, *dense2_ = nullptr;     // codes-only form of the packed buffers (64 characters per 16 bytes), nullptr = none
-  uint32_t *nsmap1_ = nullptr, *nsmap2_ = nullptr;     // one bit per 64-character superblock: holds a non-symbol
-  uint32_t *prm_bad_ = nullptr;                        // raised by k_chain_params when a value does not fit the records; nullptr = no records
-  bool prm_chars_ = true;                              // the records carry the chains' first 32 characters
-  const ulonglong2 *pre_prm_ = nullptr;                // launch_search: the sub-batch's records made for the whole batch already
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false, team_tail_ = true;
   bool wide_ = false;                  // n >= 2^32: 36-bit SA entries and the WIDE search kernel
   uint64_t pool_cap_ = 0;              // scratch pool of k_adjust_tail in entries (0 = 8 per read of a sub-batch)

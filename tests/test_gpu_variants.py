@@ -68,13 +68,6 @@ VARIANTS = {
     "two_search_streams": {"CFR_SEARCH_TWO": "1", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0"},
     # K-mer entries without the text position of their one row (the form before round 5)
     "ftabx_without_text_positions": {"CFR_FTABX_TEXTPOS": "0"},
-    # round 5: the chains' parameter records (k_chain_params: one gather per chain start, the strand's first 32 characters with it) - off
-    # (offsets from the arrays, the form before), without the characters, and with many sub-batches (the records of sub-batches 1.. are
-    # made on the upload stream beside the first search)
-    "chain_records_off": {"CFR_PRM": "0"},
-    "chain_records_without_first_characters": {"CFR_PRM_CHARS": "0"},
-    "chain_records_many_subbatches": {"CFR_SUBBATCH": "47", "CFR_TAPER_FLOOR": "0"},
-    "chain_records_off_many_subbatches": {"CFR_PRM": "0", "CFR_SUBBATCH": "47", "CFR_TAPER_FLOOR": "0"},
 }
 
 
@@ -96,8 +89,7 @@ def test_parity_suite_under_switches(name):
                                         ("post_stage_overlapped", {"CFR_TAIL_STREAM": "1", "CFR_SUBBATCH": "20000"}),
                                         ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"}),
                                         ("post_fast", {"CFR_POST_FAST": "1", "CFR_SUBBATCH": "20000"}), ("post_fast_k5", {"CFR_POST_FAST": "1", "CFR_TEST_K": "5"}),
-                                        ("search_wave_tiles", {"CFR_SEARCH_DYN": "2", "CFR_SUBBATCH": "20000"}), ("search_static", {"CFR_SEARCH_DYN": "0"}),
-                                        ("chain_records_off", {"CFR_PRM": "0", "CFR_SUBBATCH": "20000"}), ("chain_records_no_chars", {"CFR_PRM_CHARS": "0", "CFR_SUBBATCH": "20000"})])
+                                        ("search_wave_tiles", {"CFR_SEARCH_DYN": "2", "CFR_SUBBATCH": "20000"}), ("search_static", {"CFR_SEARCH_DYN": "0"})])
 def test_many_strain_workload_under_switches(name, extra):
     """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
     tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""

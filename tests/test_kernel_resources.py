@@ -34,10 +34,7 @@ BUDGET = {
     "k_search_chains_v2<2, false, true, false>": (128, 0),
     "k_search_chains_v2<2, false, true, true>": (128, 0),
     "k_search_chains_v2<4, false, true, false>": (128, 0),
-    # (pairs, 36-bit, drawn chains: 68 bytes of private segment are RESERVED since the dense read form added four kernel arguments - slots of
-    #  scalar registers the compiler then kept in lanes of a vector register after all; the kernel has no scratch instruction, see
-    #  test_no_scratch_instruction_in_the_search)
-    "k_search_chains_v2<4, false, true, true>": (128, 68),
+    "k_search_chains_v2<4, false, true, true>": (128, 0),
     # translated search: the default instantiation has none; the 80-register one (6 blocks per CU) spills two loop invariants
     "k_search_prot_sm<1, 1>": (96, 0),
     "k_search_prot_sm<2, 1>": (96, 0),
@@ -152,8 +149,9 @@ def test_the_guard_refuses_the_array_in_the_text_step(tmp_path):
 
 
 def test_no_scratch_instruction_in_the_search(tmp_path):
-    """The one search instantiation with a private segment (pairs, 36-bit, drawn chains) reserves it without using it: its assembly
-    holds no scratch instruction."""
+    """The largest search instantiation (pairs, 36-bit, drawn chains - the one closest to its limits of scalar registers; an experiment of
+    round 5 with four more kernel arguments gave it a RESERVED private segment of 68 bytes and no access to it): its assembly holds no
+    scratch instruction."""
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
     src = os.path.join(str(tmp_path), "one.hip")
