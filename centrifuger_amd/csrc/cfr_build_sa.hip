@@ -261,7 +261,12 @@ void build_sa_products(const uint8_t *text, uint64_t n, int device, uint32_t sam
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) throw HipError{"index build: no HIP device (the writer has no CPU path)", -1};
   if (device < 0 || device >= count) throw HipError{"index build: device ordinal out of range", -1};
   if (n < 64) throw HipError{"index build: text shorter than 64 symbols", -2};
-  if (n + (1ull << 27) >= (1ull << 36)) throw HipError{"index build: texts of 2^36 symbols and more are beyond this single-GPU writer", -2};
+  {
+    // (test hook, behind CFR_DEBUG_ENV: CFR_BUILD_LIMIT_LOG2 lowers the size this writer refuses at, so that a test walks the refusal on a small text)
+    uint64_t limit = 1ull << 36;
+    if (getenv("CFR_DEBUG_ENV") && atoi(getenv("CFR_DEBUG_ENV")) && getenv("CFR_BUILD_LIMIT_LOG2")) limit = 1ull << std::min(36, std::max(8, atoi(getenv("CFR_BUILD_LIMIT_LOG2"))));
+    if (n + (limit >> 9) >= limit) throw HipError{"index build: texts of 2^36 symbols and more are beyond this single-GPU writer", -2};
+  }
   if (w < 1 || w > 16) throw HipError{"index build: ftab width must be in 1..16", -2};
   BCHECK(hipSetDevice(device));
   hipStream_t st = nullptr;      // default stream: everything here is sequential

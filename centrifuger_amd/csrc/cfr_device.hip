@@ -418,7 +418,11 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   uint32_t log4n = 0;
   while (log4n < 31 && (1ull << (2 * (log4n + 1))) <= h.n) ++log4n;
   // (a protein index: u32 suffix array and one byte of text per symbol, below 2^32 symbols)
-  const bool text_possible = h.n >= 64 && h.n < (protein ? 0xfffffff0ull : (1ull << 36)) && !layout_rb;
+  // (test hook CFR_TEXT_LIMIT_LOG2: the size from which an image loads WITHOUT text mode - 36-bit suffix-array entries end at 2^36 rows -
+  //  lowered, so that a test walks that branch on a small index)
+  uint64_t text_limit = protein ? 0xfffffff0ull : (1ull << 36);
+  if (const char *e = dbg_env("CFR_TEXT_LIMIT_LOG2")) text_limit = std::min<uint64_t>(text_limit, 1ull << std::min(36, std::max(6, atoi(e))));
+  const bool text_possible = h.n >= 64 && h.n < text_limit && !layout_rb;
   bool text_want = text_possible && (opt.text_mode < 0 ? !fast_load : opt.text_mode != 0);
   if (const char *e = dbg_env("CFR_TEXT_MODE")) text_want = text_possible && atoi(e) != 0;
   const double sa_bytes = (double)h.n * (wide_ ? 4.5 : 4.0), text_tab_bytes = sa_bytes + (double)h.n * (protein ? 1.0 : 0.25);
