@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the switches below (CFR_DENSE, CFR_PRM) exist in the library of commit e774bae only - the shipped kernel has neither form (profiles/HISTORY.md section 9)
 # round 5: the dense read form (64 characters per 16-byte load) and the chains' parameter records (one gather per chain start instead of two)
 # against the build without them, on one box, alternating: CFR_DENSE=1 (both, the default) | CFR_DENSE=0 (records only) | CFR_PRM=0 (neither).
 # Also the iteration mix of the search (CFR_SEARCH_PROF=1: block loads per read) for the first and the last setting.

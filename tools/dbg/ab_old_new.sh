@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: tools/dbg/libcfr_hip_old.so is not kept in the tree: build it from the commit to compare with (git archive <commit> centrifuger_amd/csrc | tar -x -C /tmp/old; hipcc -c cfr_device.hip there; link with today's other objects as tools/dbg/build_variant.sh does)
 # round 5: the search kernel of this commit against the one of the round's start (tools/dbg/libcfr_hip_old.so: the device translation unit of
 # d726953 linked with today's other objects), alternating on one box: cfg2, pairs, long reads, 20 strains, and the 36-bit kernel on an 8 Gbp
 # index (150 bp and long reads).  First the iteration mix of today's kernel.

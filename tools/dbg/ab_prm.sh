@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: the switches below (CFR_PRM, CFR_PRM_CHARS) exist in the library of commit e774bae only - the shipped kernel reads its chains' offsets from the arrays (profiles/HISTORY.md section 9)
 # round 5: the chains' parameter records with the strands' first 32 characters (a chain looks up its first K-mer in the iteration it is
 # taken in) | records without the characters (CFR_PRM_CHARS=0) | no records (CFR_PRM=0: offsets from the arrays), alternating on one box;
 # the iteration mix of the search for the first and the last setting.
