@@ -1524,17 +1524,22 @@ def main():
         # the 15 GB .1.cfr through the page cache into 8 private copies) against one process alone.  (The device half - 8 images
         # derived side by side - needs 8 GPUs.)
         try:
-            code = ("import sys,time; sys.path.insert(0, %r); from centrifuger_amd import capi; t0=time.time(); i=capi.Index(%r); d=i.digest(); print(time.time()-t0, d)" % (ROOT, prefix))
+            # (round 5: cfr_index_open and the digest timed apart - the open leaves the bit strings in the file's mapping and is what a
+            #  rank waits for before it starts uploading; the digest reads all 15 GB and was most of the figure rounds 3-4 reported)
+            code = ("import sys,time; sys.path.insert(0, %r); from centrifuger_amd import capi; t0=time.time(); i=capi.Index(%r); t1=time.time(); d=i.digest(); print(t1-t0, time.time()-t0, d)" % (ROOT, prefix))
             def opens(k_):
                 t0_ = time.time()
                 ps = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for _ in range(k_)]
                 outs = [p_.communicate()[0].decode().split() for p_ in ps]
-                return time.time() - t0_, [float(o_[0]) for o_ in outs if len(o_) == 2], {o_[1] for o_ in outs if len(o_) == 2}
-            w1, t1, d1 = opens(1)
-            w8, t8, d8 = opens(8)
-            out["multi_rank_load"] = {"index_open_alone_s": t1[0] if t1 else None, "index_open_8_at_once_s_each": t8, "wall_8_at_once_s": w8,
+                outs = [o_ for o_ in outs if len(o_) == 3]
+                return time.time() - t0_, [float(o_[0]) for o_ in outs], [float(o_[1]) for o_ in outs], {o_[2] for o_ in outs}
+            w1, t1, td1, d1 = opens(1)
+            w8, t8, td8, d8 = opens(8)
+            out["multi_rank_load"] = {"index_open_alone_s": t1[0] if t1 else None, "index_open_8_at_once_s_each": t8,
+                                      "open_plus_digest_alone_s": td1[0] if td1 else None, "open_plus_digest_8_at_once_s_each": td8, "wall_8_at_once_s": w8,
                                       "digests_equal": len(d1 | d8) == 1 and len(t8) == 8,
-                                      "note": "cfr_index_open of this index in 1 process and in 8 processes started together (process start and imports included in the wall figure, not in the per-open ones)"}
+                                      "note": "cfr_index_open of this index in 1 process and in 8 processes started together; open_plus_digest adds cfr_index_digest, which reads "
+                                              "every array of the 15 GB file (the figure rounds 3-4 reported as the open); process start and imports are in the wall figure only"}
         except Exception as e:
             out["multi_rank_load"] = {"error": repr(e)}
     # ---- the live PMC passes need the GPU to themselves (the K-mer table is sized from the free HBM): this process lets go of

@@ -41,11 +41,13 @@ class Cursor {
     }
     return kept_;
   }
-  // n words at the cursor: left in the mapping when they are 8-byte aligned there (and the caller allows it), copied otherwise
+  // n words at the cursor: left in the mapping when the caller allows it, copied otherwise.  (Until round 5 only strings that stood 8-byte
+  // aligned in the file were left there - and none does: the header's one-byte lastChr puts every bit string of a nucleotide index at an
+  // odd offset, so every "mapped" open copied its 12 GB at 40 Gbp after all.  RawWords reads its words bytewise now.)
   void words(RawWords &w, size_t n, bool may_map, size_t extra_zero_words = 0) {
     need(n * 8);
-    if (may_map && n && (reinterpret_cast<uintptr_t>(base_ + pos_) & 7u) == 0 && size_ - pos_ >= (n + extra_zero_words) * 8) {
-      w.map(reinterpret_cast<const uint64_t *>(base_ + pos_), n + extra_zero_words);     // (the words behind it: whatever the file holds there - see the caller)
+    if (may_map && n && size_ - pos_ >= (n + extra_zero_words) * 8) {
+      w.map(base_ + pos_, n + extra_zero_words);     // (the words behind it: whatever the file holds there - see the caller)
       pos_ += n * 8;
       return;
     }
@@ -528,7 +530,7 @@ uint64_t index_digest(const HostIndex &h) {
   if (!h.prot.enabled) { wavelet(h.wavelet_seq); wavelet(h.run_block_seq); }
   num((uint64_t)h.sample_rate); num(h.sample_size); num(h.precompute_width); num(h.precompute_size); num(h.adjusted_sa0);
   num((uint64_t)h.sampled_bits); num(h.sampled_n);
-  mix(h.sampled_words.data(), h.sampled_words.size() * 8);
+  mix(h.sampled_words.data(), ceil_div(h.sampled_n * (uint64_t)h.sampled_bits, 64) * 8);      // (not the two words behind them: zeros in a copy, the file's next bytes in the mapping)
   mix(h.ftab.data(), h.ftab.size() * 8);
   num((uint64_t)h.selected_filter_rate);
   mix(h.selected_rows.data(), h.selected_rows.size() * 8);

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "../../include/cfr_hip.h"
@@ -32,15 +33,18 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 class RawWords {
  public:
-  const uint64_t *data() const { return p_; }
+  // the words as BYTES: a mapped string stands where the file has it, and the .cfr format aligns nothing (a one-byte field in the header
+  // leaves every bit string of a nucleotide index at an odd offset), so nothing may take this pointer for a uint64_t array - copies,
+  // comparisons and uploads go through it bytewise, single words through operator[]
+  const void *data() const { return p_; }
   size_t size() const { return n_; }
   bool empty() const { return n_ == 0; }
-  const uint64_t &operator[](size_t i) const { return p_[i]; }
+  uint64_t operator[](size_t i) const { uint64_t v; memcpy(&v, static_cast<const char *>(p_) + 8 * i, 8); return v; }     // (an unaligned load where the string is mapped)
   bool mapped() const { return n_ != 0 && own_.empty(); }
-  void map(const uint64_t *q, size_t n) { own_.clear(); p_ = q; n_ = n; }                       // n words at q, which outlive this object
+  void map(const void *q, size_t n) { own_.clear(); p_ = q; n_ = n; }                          // n words at q, which outlive this object
   uint64_t *alloc(size_t n) { own_.resize(n); p_ = own_.data(); n_ = n; return own_.data(); }   // n words of its own, not initialised
  private:
-  const uint64_t *p_ = nullptr;
+  const void *p_ = nullptr;
   size_t n_ = 0;
   std::vector<uint64_t, NoInitAlloc<uint64_t>> own_;
 };
