@@ -91,7 +91,7 @@ EXPORTS = [
     "cfr_rank_batch", "cfr_backward_search_batch", "cfr_locate_rows", "cfr_search_batch", "cfr_classify_batch",
     "cfr_classify_batch_resident", "cfr_last_batch_stats", "cfr_classify_from_hits", "cfr_dust_mask_batch",
     "cfr_format_tsv", "cfr_tsv_header", "cfr_host_alloc", "cfr_host_free",
-    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest", "cfr_pack_reads", "cfr_classify_batch_packed",
+    "cfr_classify_batch_submit", "cfr_classify_batch_wait", "cfr_compact_wide_reads", "cfr_index_digest", "cfr_index_mapped_bytes", "cfr_pack_reads", "cfr_classify_batch_packed",
     "cfr_classify_batch_expanded", "cfr_classify_from_hits_expanded", "cfr_format_tsv_expanded", "cfr_tsv_header_expanded",
 ]
 
@@ -223,6 +223,12 @@ class Index:
         d = C.c_uint64(0)
         _check(lib().cfr_index_digest(self._h, C.byref(d)))
         return d.value
+
+    def mapped_bytes(self):
+        """cfr_index_mapped_bytes: (bytes of bit strings read from the file's mapping, bytes held as private copies)"""
+        m, c = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().cfr_index_mapped_bytes(self._h, C.byref(m), C.byref(c)))
+        return m.value, c.value
 
     def close(self):
         if self._h:

@@ -133,6 +133,19 @@ cfr_status cfr_index_digest(const cfr_index *idx, uint64_t *digest) {
   return CFR_OK;
 }
 
+cfr_status cfr_index_mapped_bytes(const cfr_index *idx, uint64_t *mapped, uint64_t *copied) {
+  if (!idx || !mapped || !copied) return bad_arg("cfr_index_mapped_bytes: null argument");
+  const cfr::HostIndex &h = *idx->h;
+  uint64_t m = 0, c = 0;
+  auto add = [&](const cfr::RawWords &w) { (w.mapped() ? m : c) += (uint64_t)w.size() * 8; };
+  add(h.use_run_block.bits);
+  for (int k = 0; k < 3; ++k) { add(h.wavelet_seq.node[k].bits); add(h.run_block_seq.node[k].bits); }
+  add(h.sampled_words);
+  *mapped = m;
+  *copied = c;
+  return CFR_OK;
+}
+
 cfr_status cfr_device_count(int *count) {
   if (!count) return bad_arg("cfr_device_count: null argument");
   int c = 0;

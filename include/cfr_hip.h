@@ -121,6 +121,11 @@ cfr_status cfr_index_get_info(const cfr_index *idx, cfr_index_info *info);
  * Two opens of the same files with the same parameters give the same value (what the open/destroy stress test asserts); no
  * reference counterpart. */
 cfr_status cfr_index_digest(const cfr_index *idx, uint64_t *digest);
+/* How many bytes of the index's bit strings this handle reads straight from the read-only mapping of the .1.cfr file (the ranks of a node
+ * share those pages through the page cache) and how many it holds as private copies.  A nucleotide index opened normally maps all of
+ * them; a protein index is decoded into the process and maps none.  No reference counterpart (FMIndex::Load reads everything,
+ * FMIndex.hpp:588-606). */
+cfr_status cfr_index_mapped_bytes(const cfr_index *idx, uint64_t *mapped, uint64_t *copied);
 
 cfr_status cfr_device_count(int *count);
 cfr_status cfr_device_index_create(const cfr_index *idx, int device, cfr_dev_index **out);
