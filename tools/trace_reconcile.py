@@ -27,7 +27,7 @@ def main(db_path, inner_path, out=None):
             blit_calls += calls / steps
             blit_ms += ms
         lines.append(f"{calls:>6} {calls/steps:>9.1f} {ms:>12.4f} {avg/1e3:>10.2f} {vg or 0:>5} {lds or 0:>6} {scr or 0:>7}  {name[:110]}")
-    lines.append(f"# sum of all dispatch durations per step: {per_step_total:.3f} ms (dispatches on different streams overlap: the sum may exceed the step's wall time; the search + post-stage kernels do not overlap each other)")
+    lines.append(f"# sum of all dispatch durations per step: {per_step_total:.3f} ms (dispatches on different streams overlap - the post stage of a sub-batch runs BESIDE the search of the next one, and k_adjust_tail's duration here is mostly its wait for wave slots under that search - so the sum exceeds the step's wall time; under the profiler the step itself is ~35 % longer than unprofiled)")
     lines.append(f"# runtime blits (copyBuffer / fillBuffer: the small device-side copies and memsets the library enqueues): {blit_calls:.1f} dispatches, {blit_ms:.4f} ms of dispatch time per step")
     text = "\n".join(lines) + "\n"
     if out:
