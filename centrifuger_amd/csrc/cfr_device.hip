@@ -668,6 +668,38 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
   }
   lap("locate memo");
+  // ---- K-mer COUNT table (cfr_kernels.hip.inc, profiles/HISTORY.md section 10): one character more than the derived K-mer table in 0.67 bytes
+  // per entry, for the images whose K-mer table stops short of log4(n) + 2 (40 Gbp: K = 16, 9.3 expected rows per random K-mer).
+  // Only with CFR_KTAB=1 (behind CFR_DEBUG_ENV): parity-green on the golden indexes and +10 % on the scaled model of 40 Gbp (profiles/
+  // r5z_ktab_model.txt), not yet run at 40 Gbp.  CFR_KTAB_CHECK=1 compares a sample of keys with the search core.
+  ktab_ = nullptr;
+  if (const char *e = dbg_env("CFR_KTAB")) if (atoi(e) != 0 && wide_ && !protein && !layout_rb && view_.ftabx && view_.ftabx_width >= view_.ftab_width && view_.ftabx_width < 24) try {
+    const uint32_t KT = view_.ftabx_width + 1;
+    const uint64_t keys = 1ull << (2 * KT), lines = (keys + kKtabKeys - 1) / kKtabKeys;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)lines * 64.0 + 14e9 > (double)free_b) throw HipError{"no room for the K-mer count table", -2};
+    uint64_t *d_tab = dev_alloc<uint64_t>(lines * 8);
+    k_build_ktab<<<(unsigned)std::min<uint64_t>((lines + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, KT, lines, d_tab);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    if (dbg_env("CFR_KTAB_CHECK") && atoi(dbg_env("CFR_KTAB_CHECK"))) {
+      unsigned long long *d_cnt = dev_alloc<unsigned long long>(2), h_cnt[2] = {0, 0};
+      HIP_CHECK(hipMemset(d_cnt, 0, 16));
+      const uint64_t stride = std::max<uint64_t>(1, keys >> 24);            // ~16 M keys
+      k_check_ktab<<<4096, 256, 0, stream_>>>(view_, d_tab, KT, stride, d_cnt, d_cnt + 1);
+      HIP_CHECK(hipGetLastError());
+      HIP_CHECK(hipMemcpy(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[ktab] K + 1 = %u: %llu of %llu sampled keys answered by the count table, %llu disagree with the search core\n", KT, h_cnt[1],
+              (unsigned long long)((keys + stride - 1) / stride), h_cnt[0]);
+      if (h_cnt[0]) throw HipError{"K-mer count table disagrees with the search core", -3};
+    }
+    ktab_ = d_tab;
+  } catch (const HipError &err) {
+    (void)hipGetLastError();
+    ktab_ = nullptr;
+    if (err.code == -3) throw;                 // (a table that is wrong is an error; one that does not fit is simply not there)
+  }
+  lap("K-mer count table");
   {
     // what a sub-batch's buffers may take: 40 % of the HBM still free now that the image stands, at most 32 GB (cut_pieces)
     size_t free_b = 0, total_b = 0;
@@ -888,6 +920,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
     sv.sa = text_hits ? (wide_ ? view_.sa36 : view_.sa32) : nullptr;
     sv.ftabx_e8 = view_.ftabx_e8;
+    sv.ktab = ktab_;
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
@@ -942,6 +975,12 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
+    } else if (wide && ktab_ != nullptr) {     // the instantiations that start a search with the K-mer count table
+#define CFR_LAUNCH_SEARCH_KTAB(CPR_, DYN_) \
+      k_search_chains_v2<CPR_, false, true, DYN_, true><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, nullptr, d_ctr, dyn_chunk)
+      if (paired) { if (dyn) CFR_LAUNCH_SEARCH_KTAB(4, true); else CFR_LAUNCH_SEARCH_KTAB(4, false); }
+      else { if (dyn) CFR_LAUNCH_SEARCH_KTAB(2, true); else CFR_LAUNCH_SEARCH_KTAB(2, false); }
+#undef CFR_LAUNCH_SEARCH_KTAB
     } else if (wide) {
       if (paired) { if (dyn) CFR_LAUNCH_SEARCH(4, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(4, false, true, false, nullptr); }
       else { if (dyn) CFR_LAUNCH_SEARCH(2, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(2, false, true, false, nullptr); }

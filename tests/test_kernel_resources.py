@@ -35,6 +35,11 @@ BUDGET = {
     "k_search_chains_v2<2, false, true, true>": (128, 0),
     "k_search_chains_v2<4, false, true, false>": (128, 0),
     "k_search_chains_v2<4, false, true, true>": (128, 0),
+    # the instantiations that start a search with the K-mer count table (round 5, CFR_KTAB=1: profiles/r5z_ktab_model.txt)
+    "k_search_chains_v2<2, false, true, false, true>": (128, 0),
+    "k_search_chains_v2<2, false, true, true, true>": (128, 0),
+    "k_search_chains_v2<4, false, true, false, true>": (128, 0),
+    "k_search_chains_v2<4, false, true, true, true>": (128, 0),
     # translated search: the default instantiation has none; the 80-register one (6 blocks per CU) spills two loop invariants
     "k_search_prot_sm<1, 1>": (96, 0),
     "k_search_prot_sm<2, 1>": (96, 0),
@@ -86,6 +91,7 @@ def probe(kernels, tmp, name, defines=()):
     out = {}
     for mangled, dem in zip(rows, names):
         dem = re.sub(r"^void ", "", re.sub(r"\(.*", "", dem)).replace("cfr::", "")
+        dem = re.sub(r"(k_search_chains_v2<\d, \w+, \w+, \w+), false>", r"\1>", dem)      # (the fifth parameter, KTAB, at its default)
         out[dem] = (rows[mangled]["VGPRs"], rows[mangled]["ScratchSize"], rows[mangled]["Occupancy"])
     return out
 
