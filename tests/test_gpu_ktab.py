@@ -8,7 +8,6 @@ import os
 
 import pytest
 
-import oracle_lib as ora
 from centrifuger_amd import capi
 from conftest import GOLDEN
 from test_gpu_limits import env
@@ -42,18 +41,14 @@ def test_tsv_equals_reference_with_the_count_table(case, e8, golden_dir):
 
 
 @pytest.mark.parametrize("width", [7, 9, 12])
-def test_hit_lists_equal_oracle_for_several_table_widths(width, golden_dir):
+def test_tsv_equals_reference_for_several_table_widths(width, golden_dir):
     """the count table is one character wider than the derived K-mer table: K = 7, 9, 12 -> K + 1 = 8, 10, 13 on a 60 kbp text covers tables
     in which nearly every entry occurs, about a quarter, and almost none"""
     case = "f6.se_nodust"
     c = MAN["cases"][case]
-    kw = _case_kw(c["args"])
-    idx, dev = _open(golden_dir, c["index"], {"CFR_FTABX_WIDTH": width, "CFR_FTABX_E8": 1}, **kw)
-    o = ora.OracleIndex(os.path.join(golden_dir, c["index"]), max_result=kw.get("max_result", 1), min_hit_len=kw.get("min_hit_len", 0),
-                        hitk_factor=kw.get("max_result_per_hit_factor", 40))
+    idx, dev = _open(golden_dir, c["index"], {"CFR_FTABX_WIDTH": width, "CFR_FTABX_E8": 1}, **_case_kw(c["args"]))
     ids, b1, o1, b2, o2 = _load_case_reads(c["args"], golden_dir)
     results, matches = dev.classify(b1, o1, b2, o2)
     out = capi.tsv_header() + b"".join(idx.format_tsv(ids[i], results[i], matches) for i in range(len(ids)))
     assert out == open(os.path.join(GOLDEN, "tsv", case + ".tsv"), "rb").read()
-    o.close()
     dev.close()
