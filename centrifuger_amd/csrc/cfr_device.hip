@@ -683,14 +683,15 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipStreamSynchronize(stream_));
     if (dbg_env("CFR_KTAB_CHECK") && atoi(dbg_env("CFR_KTAB_CHECK"))) {
-      unsigned long long *d_cnt = dev_alloc<unsigned long long>(2), h_cnt[2] = {0, 0};
-      HIP_CHECK(hipMemset(d_cnt, 0, 16));
-      const uint64_t stride = std::max<uint64_t>(1, keys >> 24);            // ~16 M keys
-      k_check_ktab<<<4096, 256, 0, stream_>>>(view_, d_tab, KT, stride, d_cnt, d_cnt + 1);
+      unsigned long long *d_cnt = dev_alloc<unsigned long long>(6), h_cnt[6] = {0, 0, 0, 0, 0, 0};
+      HIP_CHECK(hipMemsetAsync(d_cnt, 0, 48, stream_));       // (on the image's stream: it does not synchronize with the null stream)
+      const uint64_t stride = std::max<uint64_t>(1, keys >> 24) | 1ull;      // ~16 M keys, odd: no common factor with the digit structure
+      k_check_ktab<<<4096, 256, 0, stream_>>>(view_, d_tab, KT, stride, d_cnt, d_cnt + 1, d_cnt + 2);
       HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipMemcpy(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost));
-      fprintf(stderr, "[ktab] K + 1 = %u: %llu of %llu sampled keys answered by the count table, %llu disagree with the search core\n", KT, h_cnt[1],
-              (unsigned long long)((keys + stride - 1) / stride), h_cnt[0]);
+      HIP_CHECK(hipStreamSynchronize(stream_));                // (round 5's runs read the counters while the kernel was still counting: their
+      HIP_CHECK(hipMemcpy(h_cnt, d_cnt, 48, hipMemcpyDeviceToHost));   //  "answered" figures are partial; the parity tests are the evidence of those runs)
+      fprintf(stderr, "[ktab] K + 1 = %u: %llu of %llu sampled keys answered by the count table, %llu disagree with the search core; bytes: %llu to the K-mer table, "
+              "%llu counts, %llu 'does not occur', %llu poisoned\n", KT, h_cnt[1], (unsigned long long)((keys + stride - 1) / stride), h_cnt[0], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5]);
       if (h_cnt[0]) throw HipError{"K-mer count table disagrees with the search core", -3};
     }
     ktab_ = d_tab;

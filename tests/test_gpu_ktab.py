@@ -1,8 +1,8 @@
 """The K-mer COUNT table (cfr_kernels.hip.inc: k_build_ktab, the KTAB instantiations of k_search_chains_v2; profiles/HISTORY.md section 10,
 profiles/r5z_ktab_model.txt) is OFF unless CFR_KTAB=1: written in the last hours of round 5, it ran on a GPU for 70 seconds in all - these
 69 tests passed for each of its three encodings and the byte form gained 10 % on the scaled model of 40 Gbp - and has not seen a 40 Gbp
-index.  The tests: the table against the search core on every sampled key (CFR_KTAB_CHECK=1 makes a disagreement an error at load), then
-the reference's TSVs through the kernels that use it, on the 36-bit image forced on the golden indexes, for several table widths.
+index.  The tests: the table against the search core on a sample of keys (CFR_KTAB_CHECK=1 makes a disagreement an error at load; in round
+5's runs that check read its counters too early, so the TSVs are what those runs prove), then the reference's TSVs through the kernels that use it, on the 36-bit image forced on the golden indexes, for several table widths.
 Skipped unless CFR_TEST_KTAB=1 (CFR_TEST_KTAB=1 python -m pytest tests/test_gpu_ktab.py -m gpu) until the path is switched on."""
 import os
 
