@@ -36,6 +36,142 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+COMPACT_LIMIT = 4096      # bytes of the ONE line the driver parses (round 5's 29 KB line was not parsed: BENCH_r05 `parsed: null`)
+
+
+def _r(v, nd=4):
+    """a number short enough for the compact line (4 significant digits), None for anything that is not a finite number"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, int):
+        return v
+    try:
+        f = float(v)
+    except (TypeError, ValueError):
+        return None
+    if f != f or f in (float("inf"), float("-inf")):
+        return None
+    return float(f"{f:.{nd}g}")
+
+
+def compact_line(out):
+    """The line the driver reads: the contract's keys, `roofline` and `cpu_baseline` as flat objects of scalars, the parity booleans and ONE scalar
+    per sub-result - a few hundred bytes each, <= COMPACT_LIMIT in all.  Everything else (notes, per-kernel counters, iteration mixes) goes to the
+    detail file / stderr (`emit_line`).  tests/test_bench_static.py builds this from stored detail objects and checks size, keys and finiteness."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = {k: (v[:200] if isinstance(v, str) else v) for k, v in cfg.items() if k in ("workload", "index_bp", "reads_per_step_per_gpu", "read_len", "parallelism", "timed_entry")}
+    roof = out.get("roofline") or {}
+    line["roofline"] = {"bound": roof.get("bound"), "kernel": roof.get("kernel"), "kernel_ms": _r(roof.get("kernel_ms")), "unit": roof.get("unit"), "peak": _r(roof.get("peak")),
+                        "achieved": _r(roof.get("achieved")), "frac": _r(roof.get("frac")),
+                        "achieved_counter_traffic": _r(roof.get("achieved_counter_traffic")), "frac_counter_traffic": _r(roof.get("frac_counter_traffic")),
+                        "frac_useful_bytes": _r(roof.get("frac_useful_bytes")), "gather_frac": _r(g(roof, "gather", "frac") if roof.get("gather") else roof.get("gather_ceiling_frac")),
+                        "l2_hit": _r(roof.get("l2_hit")), "x_reference_algorithm": _r(roof.get("x_reference_algorithm")), "traffic": _r(roof.get("traffic"), 6),
+                        "requests_per_read": _r(roof.get("fabric_read_requests_per_read")), "fetched_over_useful": _r(roof.get("fetched_over_useful")),
+                        "valu_per_wave_iteration": _r(g(roof, "instruction_stream", "valu_wave_instructions_per_wave_iteration")),
+                        "valu_issue_frac": _r(g(roof, "instruction_stream", "valu_issue_frac")), "kernel_ms_alone": _r(roof.get("kernel_ms_alone"))}
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb.get("value"), 6), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:160],
+                                "classify_only_value": _r(g(cb, "classify_only", "value"), 6), "classify_only_cores": g(cb, "classify_only", "cores")}
+    par = {}
+    for k, v in (("tsv_identical_to_reference", g(out, "parity", "tsv_identical_to_reference")),
+                 ("timed_entry_tsv_identical_to_reference_no_dust", g(out, "parity", "timed_entry_tsv_identical_to_reference_no_dust")),
+                 ("reads_vs_reference", g(out, "parity", "reads")), ("equals_oracle", g(out, "parity_oracle", "equals_oracle")),
+                 ("reads_vs_oracle", g(out, "parity_oracle", "reads")),
+                 ("host_entries_equal_resident", g(out, "pcie_inclusive", "host_entry_equals_resident_entry")),
+                 ("cli_tsv_identical_to_reference", g(out, "e2e_cli", "tsv_identical_to_reference")),
+                 ("cli_100m_md5_equals_reference_rows", g(out, "e2e_cli_100m", "md5_equals_reference_rows")),
+                 ("cli_100m_fastq_md5_equals_reference_rows", g(out, "e2e_cli_100m_fastq", "md5_equals_reference_rows"))):
+        if v is not None:
+            par[k] = v
+    line["parity"] = par
+    st = out.get("stage_ms") or {}
+    line["stage_ms"] = {k: _r(st.get(k)) for k in ("search_ms", "tail_ms", "total_ms") if k in st}
+    if out.get("classified_fraction") is not None:
+        line["classified_fraction"] = _r(out["classified_fraction"], 7)
+    sub = {}
+    if g(out, "with_device_sdust", "value") is not None:
+        sub["value_default_options"] = _r(out["with_device_sdust"]["value"], 6)      # SDUST on (the reference's default), on the device
+        sub["k_dust_ms"] = _r(g(out, "with_device_sdust", "roofline", "kernel_ms"))
+    for k in ("pinned_value", "packed_pinned_value"):
+        if g(out, "pcie_inclusive", k) is not None:
+            sub["pcie_" + k] = _r(out["pcie_inclusive"][k], 6)
+    if g(out, "e2e_cli_100m", "value") is not None:
+        sub["e2e_cli_100m"] = _r(out["e2e_cli_100m"]["value"], 6)
+    if g(out, "e2e_cli_100m_fastq", "value") is not None:
+        sub["e2e_cli_100m_fastq"] = _r(out["e2e_cli_100m_fastq"]["value"], 6)
+    if g(out, "e2e_cli", "speedup") is not None:
+        sub["e2e_cli_speedup_vs_reference"] = _r(out["e2e_cli"]["speedup"])
+    ps = g(out, "post_stage", "roofline") or {}
+    if ps:
+        sub["post_stage"] = {"ms_alone": _r(ps.get("ms_alone_per_step")), "ms_in_step": _r(ps.get("ms_inside_the_step_overlapped")), "frac_counter_traffic": _r(ps.get("frac_counter_traffic"))}
+    for name, o in (out.get("other_configs") or {}).items():
+        if not isinstance(o, dict):
+            continue
+        if "value" in o:
+            e = {"value": _r(o["value"], 6), "ms_per_step": _r(o.get("ms_per_step"))}
+            ok = o.get("equals_oracle")
+            if ok is not None:
+                e["equals_oracle"] = ok
+            pv = o.get("parity_vs_reference_binary") or {}
+            if pv.get("timed_entry_tsv_identical_to_reference_no_dust") is not None:
+                e["tsv_identical_to_reference"] = bool(pv.get("timed_entry_tsv_identical_to_reference_no_dust")) and pv.get("tsv_identical_to_reference") is not False
+            rf = o.get("roofline") or {}
+            if rf.get("fabric_read_requests_per_read") is not None:
+                e["requests_per_read"] = _r(rf["fabric_read_requests_per_read"])
+            if isinstance(rf.get("gather"), dict) and rf["gather"].get("frac") is not None:
+                e["gather_frac"] = _r(rf["gather"]["frac"])
+            if rf.get("frac_counter_traffic") is not None:
+                e["frac_counter_traffic"] = _r(rf["frac_counter_traffic"])
+            pst = g(o, "post_stage", "roofline") or {}
+            if pst.get("ms_alone_per_step") is not None:
+                e["post_ms_alone"], e["post_ms_in_step"] = _r(pst.get("ms_alone_per_step")), _r(pst.get("ms_inside_the_step_overlapped"))
+            sub[name] = e
+        elif "skipped" in o:
+            sub[name] = {"skipped": str(o["skipped"])[:120]}
+        else:
+            sub[name] = {"error": str(o.get("error"))[:120]}
+    line["sub_results"] = sub
+    if out.get("detail"):
+        line["detail"] = out["detail"]
+    s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    shrink = [lambda: [e.update({k: v[:32] for k, v in e.items() if isinstance(v, str)}) for e in sub.values() if isinstance(e, dict)],     # shorter error texts
+              lambda: [sub.pop(k) for k in [k for k, e in sub.items() if isinstance(e, dict) and "value" not in e and "ms_alone" not in e]],   # no error texts
+              lambda: [sub.update({k: e["value"]}) for k, e in list(sub.items()) if isinstance(e, dict) and "value" in e],                   # one scalar per sub-result
+              lambda: line.pop("sub_results", None), lambda: line.pop("stage_ms", None), lambda: line.pop("parity", None)]
+    while len(s.encode()) > COMPACT_LIMIT - 64 and shrink:       # never with today's fields on a healthy run; a run full of errors loses their texts, not the line
+        shrink.pop(0)()
+        s = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    return s
+
+
+def emit_line(out, args=None):
+    """Children of the default run (`--inner`, `--sub-result`) and `CFR_BENCH_FULL_LINE=1` print the full object (their parent parses it).  Everything
+    else prints the compact line LAST on stdout, after the full object has gone to stderr and to a detail file ($CFR_BENCH_DETAIL, else
+    gpurun_out/bench_detail_latest.json beside this file when that directory exists, else the cache directory)."""
+    full = json.dumps(out)
+    if (args is not None and (getattr(args, "inner", False) or getattr(args, "sub_result", False))) or os.environ.get("CFR_BENCH_FULL_LINE") == "1":
+        print(full, flush=True)
+        return
+    path = os.environ.get("CFR_BENCH_DETAIL")
+    if not path:
+        gdir = os.path.join(ROOT, "gpurun_out")
+        path = os.path.join(gdir if os.path.isdir(gdir) else (getattr(args, "cache", None) or "/tmp"), "bench_detail_latest.json")
+    try:
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with open(path, "w") as f:
+            f.write(full + "\n")
+        out = dict(out, detail=path if not path.startswith(ROOT) else os.path.relpath(path, ROOT))
+    except OSError as e:
+        log(f"[bench] detail file {path}: {e}")
+    sys.stderr.write("[bench] detail " + full + "\n")
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(out), flush=True)
+
+
 def build_index(args, cache, device=None):
     """Index generation is OUT of the timed path.  --builder own: the native writer behind cfr_build_index (suffix array in
     HBM, csrc/cfr_build_sa.hip; writes the same .cfr fields as the reference's builder, tests/test_gpu_build.py);
@@ -852,7 +988,7 @@ def protein_mode(torch, capi, args, device):
     if os.path.exists(prefix + ".build.json"):
         out["index"] = json.load(open(prefix + ".build.json"))
     if getattr(args, "inner", False):
-        print(json.dumps(out), flush=True)
+        emit_line(out, args)
         dev.close()
         return
     if not args.no_pmc:
@@ -901,7 +1037,7 @@ def protein_mode(torch, capi, args, device):
         out["cpu_baseline"] = {"value": nb / max(t_full - t_load, 1e-9), "unit": "reads/s", "cores": min(ncpu, 64), "kind": "reference",
                                "sample": f"first {nb} reads, oracle/_ref/centrifuger -t {min(ncpu, 64)} -k {k} on the same protein index, wall {t_full:.1f}s minus index-load run {t_load:.1f}s"}
         out["parity"] = {"reads": nb, "tsv_identical_to_reference": own == ref_tsv, "md5": hashlib.md5(own).hexdigest()}
-    print(json.dumps(out), flush=True)
+    emit_line(out, args)
     dev.close()
 
 
@@ -1622,7 +1758,7 @@ def main():
                 # rank's share of the reads - 12.5 M x 150 bp per step, 312 500 long reads per step - each in a process of its own
                 for cfg in ("cfg4", "cfg5"):
                     out["other_configs"][cfg + "_1gpu"] = sub_config_40gbp(args, cfg)
-    print(json.dumps(out), flush=True)
+    emit_line(out, args)
     if dist is not None:
         dist.destroy_process_group()
 
