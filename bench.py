@@ -94,7 +94,7 @@ def compact_line(out):
     sub = {}
     if g(out, "with_device_sdust", "value") is not None:
         sub["value_default_options"] = _r(out["with_device_sdust"]["value"], 6)      # SDUST on (the reference's default), on the device
-        sub["k_dust_ms"] = _r(g(out, "with_device_sdust", "roofline", "kernel_ms"))
+        sub["k_dust_ms"] = _r(g(out, "with_device_sdust", "roofline", "pre_step_ms_per_step_measured"))
     for k in ("pinned_value", "packed_pinned_value"):
         if g(out, "pcie_inclusive", k) is not None:
             sub["pcie_" + k] = _r(out["pcie_inclusive"][k], 6)
