@@ -38,7 +38,7 @@ inline unsigned grid_for(size_t n, int block = kBlock) { return (unsigned)((n + 
 
 enum Slot : size_t {
   S_CAP = 0, S_HITOFF, S_RAW, S_CHAINCNT, S_SCAN2, S_POOL_E, S_POOL_V, S_POOLCTL, S_POOLCTL1, S_FIN, S_FINCNT, S_FINROWS, S_FINOFF, S_HITS, S_ROWSPER, S_ROWOFF, S_ROWS,
-  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_SLOW, S_SLOW1, S_COUNT
+  S_ROWVALS, S_PACK1, S_PACK2, S_READROWS, S_READROWOFF, S_ENTRIES, S_RESULTS, S_MATCHES, S_RESULTS1, S_MATCHES1, S_SCAN, S_IN_B1, S_IN_O1, S_IN_B2, S_IN_O2, S_DUSTPOOL, S_DUSTPOOL2, S_DUSTTMP, S_DUSTTMP2, S_DUSTFLAG, S_DUSTFLAG2, S_HEAVY, S_HEAVYB, S_HEAVYB1, S_CAP1, S_HITOFF1, S_RAW1, S_CHAINCNT1, S_SCAN1, S_HEAVY1, S_CRES, S_CRES1, S_CMATCH, S_CMATCH1, S_WIDEIDX, S_WIDERES, S_WIDEMATCH, S_WIDECNT, S_PCODES1, S_PCODES2, S_CAPALL, S_HITALL, S_SCANALL, S_P0, S_P1, S_P2, S_P3, S_P4, S_P5, S_EXPPOOL, S_EXPCUR, S_SLOW, S_SLOW1, S_LIST, S_LIST1, S_LISTCTR, S_COUNT
 };
 
 }  // namespace
@@ -964,6 +964,58 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     const uint64_t nb2 = paired ? nblk2_ : 0;
 #define CFR_LAUNCH_SEARCH(CPR_, PROF_, WIDE_, DYN_, PROFPTR_) \
     k_search_chains_v2<CPR_, PROF_, WIDE_, DYN_><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, PROFPTR_, d_ctr, dyn_chunk)
+    // the two-launch form (round 6, k_search_chains_v2 STAGE 1 / 2): the state machine without wide text mode walks every chain and hands the
+    // ones whose search reaches a range of 5 .. wide_rows rows over through a list; the full state machine runs over that list
+    static const int split_env = dbg_env("CFR_SEARCH_SPLIT") ? atoi(dbg_env("CFR_SEARCH_SPLIT")) : -1;
+    const bool prof_run = dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired;
+    bool split = sv.sa != nullptr && sv.wide_rows > 4 && ktab_ == nullptr && nchains < 0xfff00000ull;
+    if (split_env >= 0) split = split && split_env != 0; else split = split && search_split_default_;
+    if (split) {
+      uint64_t *list = (uint64_t *)scratch(par ? S_LIST1 : S_LIST, (nchains + ((size_t)num_cus_ * 8 * 4 + 1) * kListChunk) * 32);
+      unsigned long long *lc = (unsigned long long *)scratch(S_LISTCTR, 64 * 8) + (par ? 8 : 0);       // [0] slots of the list, [1] / [2] the two launches' chain counters
+      HIP_CHECK(hipMemsetAsync(lc, 0, 3 * 8, sst));
+      unsigned long long *d_prof = nullptr;
+      if (prof_run) { d_prof = (unsigned long long *)scratch(S_LISTCTR, 64 * 8) + 16; HIP_CHECK(hipMemsetAsync(d_prof, 0, 32 * 8, sst)); }
+      auto both = [&](auto cpr_c, auto wide_c, auto dyn_c, auto prof_c) {
+        constexpr int C = decltype(cpr_c)::value;
+        constexpr bool W = decltype(wide_c)::value, D = decltype(dyn_c)::value, P = decltype(prof_c)::value;
+        int occ = 0;
+        unsigned first_blocks = blocks;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, false, 1>, kBlock, 0) == hipSuccess && occ > 0) {
+          int want = blocks_forced_ ? blocks_per_cu_ : std::min(occ, 8);
+          if (overlap_now_ && !blocks_forced_) want = std::min(want, 4);
+          static const int first_cap = dbg_env("CFR_FIRST_BLOCKS") ? std::max(1, atoi(dbg_env("CFR_FIRST_BLOCKS"))) : 0;
+          if (first_cap) want = std::min(occ, first_cap);
+          first_blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * std::min(occ, want)));
+        } else (void)hipGetLastError();
+        k_search_chains_v2<C, P, W, D, false, 1><<<first_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof,
+                                                                                 lc + 1, dyn_chunk, list, lc);
+        unsigned list_blocks = blocks;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, false, 2>, kBlock, 0) == hipSuccess && occ > 0)
+          list_blocks = std::min<unsigned>(list_blocks, (unsigned)(num_cus_ * occ));
+        else (void)hipGetLastError();
+        k_search_chains_v2<C, P, W, D, false, 2><<<list_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof ? d_prof + 16 : nullptr,
+                                                                                lc + 2, dyn_chunk, list, lc);
+      };
+      auto pick_dyn = [&](auto cpr_c, auto wide_c) {
+        if (prof_run) { if (dyn) both(cpr_c, wide_c, std::true_type{}, std::true_type{}); else both(cpr_c, wide_c, std::false_type{}, std::true_type{}); }
+        else { if (dyn) both(cpr_c, wide_c, std::true_type{}, std::false_type{}); else both(cpr_c, wide_c, std::false_type{}, std::false_type{}); }
+      };
+      auto pick_wide = [&](auto cpr_c) { if (wide) pick_dyn(cpr_c, std::true_type{}); else pick_dyn(cpr_c, std::false_type{}); };
+      if (paired) pick_wide(std::integral_constant<int, 4>{}); else pick_wide(std::integral_constant<int, 2>{});
+      if (prof_run) {
+        unsigned long long h_prof[32], h_lc[3];
+        HIP_CHECK(hipMemcpyAsync(h_prof, d_prof, 32 * 8, hipMemcpyDeviceToHost, sst));
+        HIP_CHECK(hipMemcpyAsync(h_lc, lc, 3 * 8, hipMemcpyDeviceToHost, sst));
+        HIP_CHECK(hipStreamSynchronize(sst));
+        static const char *names[] = {"idle", "table", "table10", "ext", "sa", "text", "text_hits", "lane_iterations", "ext_two_records", "text_rows", "block_loads", "saw", "textw"};
+        for (int k = 0; k < 2; ++k) {
+          fprintf(stderr, "[search prof %s] reads %zu list slots %llu:", k ? "stage 2" : "stage 1", n, h_lc[0]);
+          for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[16 * k + q] / (double)n);
+          fprintf(stderr, " (per read)\n");
+        }
+      }
+    } else
     if (dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired) {
       // diagnostic: iteration mix of the state machine for this launch, on stderr
       unsigned long long *d_prof = (unsigned long long *)scratch(S_P5, 16 * 8), h_prof[16];
