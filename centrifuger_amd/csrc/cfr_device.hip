@@ -673,11 +673,25 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   // Only with CFR_KTAB=1 (behind CFR_DEBUG_ENV): parity-green on the golden indexes and +10 % on the scaled model of 40 Gbp (profiles/
   // r5z_ktab_model.txt), not yet run at 40 Gbp.  CFR_KTAB_CHECK=1 compares a sample of keys with the search core.
   ktab_ = nullptr;
-  if (const char *e = dbg_env("CFR_KTAB")) if (atoi(e) != 0 && wide_ && !protein && !layout_rb && view_.ftabx && view_.ftabx_width >= view_.ftab_width && view_.ftabx_width < 24) try {
+  // Policy (round 6): 36-bit images have K capped at 16 by memory, and a random 16-mer of an index of more than 2^32 symbols occurs once or
+  // more (9 rows at 40 Gbp): every search of the strand that does not match then needs BWT extends behind its lookup.  The count table is
+  // built when it fits beside the image with the batch reserve (mode 1); when it only fits at load time, the 8-byte K-mer table it was built
+  // from is FREED afterwards (mode 2: what the count table cannot answer - a non-symbol in the window, a poisoned byte - starts from the
+  // on-disk ftab instead; at 40 Gbp: 249 GB -> 238 GB).  CFR_KTAB=0 / 1 / 2 force none / keep / drop.
+  int ktab_mode = (wide_ && !protein && !layout_rb && !fast_load && !balanced) ? -1 : 0;       // -1: decide by memory
+  if (const char *e = dbg_env("CFR_KTAB")) ktab_mode = atoi(e);
+  if (ktab_mode != 0 && wide_ && !protein && !layout_rb && view_.ftabx && view_.ftabx_width >= view_.ftab_width && view_.ftabx_width < 24) try {
     const uint32_t KT = view_.ftabx_width + 1;
     const uint64_t keys = 1ull << (2 * KT), lines = (keys + kKtabKeys - 1) / kKtabKeys;
+    const double tab_bytes = (double)lines * 64.0, kmer_bytes = (double)((view_.ftabx_e8 ? 8ull : 16ull) << (2 * view_.ftabx_width));
+    const double reserve = 14e9;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)lines * 64.0 + 14e9 > (double)free_b) throw HipError{"no room for the K-mer count table", -2};
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) throw HipError{"no memory figures for the K-mer count table", -2};
+    if (ktab_mode < 0) {
+      if (tab_bytes + reserve <= (double)free_b) ktab_mode = 1;
+      else if (tab_bytes + 2e9 <= (double)free_b && tab_bytes + reserve <= (double)free_b + kmer_bytes) ktab_mode = 2;
+      else throw HipError{"no room for the K-mer count table", -2};
+    } else if (tab_bytes + (ktab_mode == 2 ? 2e9 : reserve) > (double)free_b) throw HipError{"no room for the K-mer count table", -2};
     uint64_t *d_tab = dev_alloc<uint64_t>(lines * 8);
     k_build_ktab<<<(unsigned)std::min<uint64_t>((lines + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, KT, lines, d_tab);
     HIP_CHECK(hipGetLastError());
@@ -695,6 +709,12 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       if (h_cnt[0]) throw HipError{"K-mer count table disagrees with the search core", -3};
     }
     ktab_ = d_tab;
+    if (ktab_mode == 2) {                      // the K-mer table has served (k_build_ktab, k_check_ktab): its memory goes to the batches
+      void *kp = const_cast<uint64_t *>(view_.ftabx);
+      auto it = std::find(owned_.begin(), owned_.end(), kp);
+      if (it != owned_.end()) { owned_.erase(it); (void)hipFree(kp); view_.ftabx = nullptr; device_bytes_ -= (uint64_t)kmer_bytes + 16; }     // (ftabx_width stays: the count table is K + 1 wide)
+    }
+    if (load_timing) fprintf(stderr, "[cfr-load] K-mer count table: K + 1 = %u, %.1f GB, K-mer table %s\n", KT, tab_bytes / 1e9, view_.ftabx ? "kept" : "freed");
   } catch (const HipError &err) {
     (void)hipGetLastError();
     ktab_ = nullptr;
