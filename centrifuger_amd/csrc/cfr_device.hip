@@ -668,59 +668,6 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
     } catch (const HipError &) { (void)hipGetLastError(); view_.loc_memo = nullptr; view_.memo_shift = 0; }   // optional table
   }
   lap("locate memo");
-  // ---- K-mer COUNT table (cfr_kernels.hip.inc, profiles/HISTORY.md section 10): one character more than the derived K-mer table in 0.67 bytes
-  // per entry, for the images whose K-mer table stops short of log4(n) + 2 (40 Gbp: K = 16, 9.3 expected rows per random K-mer).
-  // Only with CFR_KTAB=1 (behind CFR_DEBUG_ENV): parity-green on the golden indexes and +10 % on the scaled model of 40 Gbp (profiles/
-  // r5z_ktab_model.txt), not yet run at 40 Gbp.  CFR_KTAB_CHECK=1 compares a sample of keys with the search core.
-  ktab_ = nullptr;
-  // Policy (round 6): 36-bit images have K capped at 16 by memory, and a random 16-mer of an index of more than 2^32 symbols occurs once or
-  // more (9 rows at 40 Gbp): every search of the strand that does not match then needs BWT extends behind its lookup.  The count table is
-  // built when it fits beside the image with the batch reserve (mode 1); when it only fits at load time, the 8-byte K-mer table it was built
-  // from is FREED afterwards (mode 2: what the count table cannot answer - a non-symbol in the window, a poisoned byte - starts from the
-  // on-disk ftab instead; at 40 Gbp: 249 GB -> 238 GB).  CFR_KTAB=0 / 1 / 2 force none / keep / drop.
-  int ktab_mode = (wide_ && !protein && !layout_rb && !fast_load && !balanced) ? -1 : 0;       // -1: decide by memory
-  if (const char *e = dbg_env("CFR_KTAB")) ktab_mode = atoi(e);
-  if (ktab_mode != 0 && wide_ && !protein && !layout_rb && view_.ftabx && view_.ftabx_width >= view_.ftab_width && view_.ftabx_width < 24) try {
-    const uint32_t KT = view_.ftabx_width + 1;
-    const uint64_t keys = 1ull << (2 * KT), lines = (keys + kKtabKeys - 1) / kKtabKeys;
-    const double tab_bytes = (double)lines * 64.0, kmer_bytes = (double)((view_.ftabx_e8 ? 8ull : 16ull) << (2 * view_.ftabx_width));
-    const double reserve = 14e9;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) throw HipError{"no memory figures for the K-mer count table", -2};
-    if (ktab_mode < 0) {
-      if (tab_bytes + reserve <= (double)free_b) ktab_mode = 1;
-      else if (tab_bytes + 2e9 <= (double)free_b && tab_bytes + reserve <= (double)free_b + kmer_bytes) ktab_mode = 2;
-      else throw HipError{"no room for the K-mer count table", -2};
-    } else if (tab_bytes + (ktab_mode == 2 ? 2e9 : reserve) > (double)free_b) throw HipError{"no room for the K-mer count table", -2};
-    uint64_t *d_tab = dev_alloc<uint64_t>(lines * 8);
-    k_build_ktab<<<(unsigned)std::min<uint64_t>((lines + 255) / 256, 1u << 22), 256, 0, stream_>>>(view_, KT, lines, d_tab);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    if (dbg_env("CFR_KTAB_CHECK") && atoi(dbg_env("CFR_KTAB_CHECK"))) {
-      unsigned long long *d_cnt = dev_alloc<unsigned long long>(6), h_cnt[6] = {0, 0, 0, 0, 0, 0};
-      HIP_CHECK(hipMemsetAsync(d_cnt, 0, 48, stream_));       // (on the image's stream: it does not synchronize with the null stream)
-      const uint64_t stride = std::max<uint64_t>(1, keys >> 24) | 1ull;      // ~16 M keys, odd: no common factor with the digit structure
-      k_check_ktab<<<4096, 256, 0, stream_>>>(view_, d_tab, KT, stride, d_cnt, d_cnt + 1, d_cnt + 2);
-      HIP_CHECK(hipGetLastError());
-      HIP_CHECK(hipStreamSynchronize(stream_));                // (round 5's runs read the counters while the kernel was still counting: their
-      HIP_CHECK(hipMemcpy(h_cnt, d_cnt, 48, hipMemcpyDeviceToHost));   //  "answered" figures are partial; the parity tests are the evidence of those runs)
-      fprintf(stderr, "[ktab] K + 1 = %u: %llu of %llu sampled keys answered by the count table, %llu disagree with the search core; bytes: %llu to the K-mer table, "
-              "%llu counts, %llu 'does not occur', %llu poisoned\n", KT, h_cnt[1], (unsigned long long)((keys + stride - 1) / stride), h_cnt[0], h_cnt[2], h_cnt[3], h_cnt[4], h_cnt[5]);
-      if (h_cnt[0]) throw HipError{"K-mer count table disagrees with the search core", -3};
-    }
-    ktab_ = d_tab;
-    if (ktab_mode == 2) {                      // the K-mer table has served (k_build_ktab, k_check_ktab): its memory goes to the batches
-      void *kp = const_cast<uint64_t *>(view_.ftabx);
-      auto it = std::find(owned_.begin(), owned_.end(), kp);
-      if (it != owned_.end()) { owned_.erase(it); (void)hipFree(kp); view_.ftabx = nullptr; device_bytes_ -= (uint64_t)kmer_bytes + 16; }     // (ftabx_width stays: the count table is K + 1 wide)
-    }
-    if (load_timing) fprintf(stderr, "[cfr-load] K-mer count table: K + 1 = %u, %.1f GB, K-mer table %s\n", KT, tab_bytes / 1e9, view_.ftabx ? "kept" : "freed");
-  } catch (const HipError &err) {
-    (void)hipGetLastError();
-    ktab_ = nullptr;
-    if (err.code == -3) throw;                 // (a table that is wrong is an error; one that does not fit is simply not there)
-  }
-  lap("K-mer count table");
   {
     // what a sub-batch's buffers may take: 40 % of the HBM still free now that the image stands, at most 32 GB (cut_pieces)
     size_t free_b = 0, total_b = 0;
@@ -941,7 +888,6 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     sv.occ = view_.occ; sv.ftab = view_.ftab; sv.ftabx = view_.ftabx; sv.text2 = view_.text2;
     sv.sa = text_hits ? (wide_ ? view_.sa36 : view_.sa32) : nullptr;
     sv.ftabx_e8 = view_.ftabx_e8;
-    sv.ktab = ktab_;
     const bool wide = wide_;
     sv.last_code = view_.last_code; sv.ftab_width = view_.ftab_width; sv.ftabx_width = view_.ftabx_width;
     sv.text_min_l = view_.text_min_l; sv.min_hit_len = view_.min_hit_len;
@@ -988,7 +934,7 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
     // ones whose search reaches a range of 5 .. wide_rows rows over through a list; the full state machine runs over that list
     static const int split_env = dbg_env("CFR_SEARCH_SPLIT") ? atoi(dbg_env("CFR_SEARCH_SPLIT")) : -1;
     const bool prof_run = dbg_env("CFR_SEARCH_PROF") && atoi(dbg_env("CFR_SEARCH_PROF")) && !paired;
-    bool split = sv.sa != nullptr && sv.wide_rows > 4 && ktab_ == nullptr && nchains < 0xfff00000ull;
+    bool split = sv.sa != nullptr && sv.wide_rows > 4 && nchains < 0xfff00000ull;
     if (split_env >= 0) split = split && split_env != 0; else split = split && search_split_default_;
     if (split) {
       uint64_t *list = (uint64_t *)scratch(par ? S_LIST1 : S_LIST, (nchains + ((size_t)num_cus_ * 8 * 4 + 1) * kListChunk) * 32);
@@ -1001,20 +947,20 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
         constexpr bool W = decltype(wide_c)::value, D = decltype(dyn_c)::value, P = decltype(prof_c)::value;
         int occ = 0;
         unsigned first_blocks = blocks;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, false, 1>, kBlock, 0) == hipSuccess && occ > 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, 1>, kBlock, 0) == hipSuccess && occ > 0) {
           int want = blocks_forced_ ? blocks_per_cu_ : std::min(occ, 8);
           if (overlap_now_ && !blocks_forced_) want = std::min(want, 4);
           static const int first_cap = dbg_env("CFR_FIRST_BLOCKS") ? std::max(1, atoi(dbg_env("CFR_FIRST_BLOCKS"))) : 0;
           if (first_cap) want = std::min(occ, first_cap);
           first_blocks = std::min<unsigned>(grid_for(nchains), (unsigned)(num_cus_ * std::min(occ, want)));
         } else (void)hipGetLastError();
-        k_search_chains_v2<C, P, W, D, false, 1><<<first_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof,
+        k_search_chains_v2<C, P, W, D, 1><<<first_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof,
                                                                                  lc + 1, dyn_chunk, list, lc);
         unsigned list_blocks = blocks;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, false, 2>, kBlock, 0) == hipSuccess && occ > 0)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_chains_v2<C, P, W, D, 2>, kBlock, 0) == hipSuccess && occ > 0)
           list_blocks = std::min<unsigned>(list_blocks, (unsigned)(num_cus_ * occ));
         else (void)hipGetLastError();
-        k_search_chains_v2<C, P, W, D, false, 2><<<list_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof ? d_prof + 16 : nullptr,
+        k_search_chains_v2<C, P, W, D, 2><<<list_blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, d_prof ? d_prof + 16 : nullptr,
                                                                                 lc + 2, dyn_chunk, list, lc);
       };
       auto pick_dyn = [&](auto cpr_c, auto wide_c) {
@@ -1048,12 +994,6 @@ DeviceIndex::SearchBuf DeviceIndex::launch_search(const uint8_t *d_b1, const uin
       fprintf(stderr, "[search prof] reads %zu lanes %u:", n, blocks * kBlock);
       for (int q = 0; q < 13; ++q) fprintf(stderr, " %s %.2f", names[q], (double)h_prof[q] / (double)n);
       fprintf(stderr, " (per read)\n");
-    } else if (wide && ktab_ != nullptr) {     // the instantiations that start a search with the K-mer count table
-#define CFR_LAUNCH_SEARCH_KTAB(CPR_, DYN_) \
-      k_search_chains_v2<CPR_, false, true, DYN_, true><<<blocks, kBlock, 0, sst>>>(sv, packed1_, d_o1, p2, o2, n, nblk1_, nb2, hit_off, raw, chain_cnt, nullptr, d_ctr, dyn_chunk)
-      if (paired) { if (dyn) CFR_LAUNCH_SEARCH_KTAB(4, true); else CFR_LAUNCH_SEARCH_KTAB(4, false); }
-      else { if (dyn) CFR_LAUNCH_SEARCH_KTAB(2, true); else CFR_LAUNCH_SEARCH_KTAB(2, false); }
-#undef CFR_LAUNCH_SEARCH_KTAB
     } else if (wide) {
       if (paired) { if (dyn) CFR_LAUNCH_SEARCH(4, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(4, false, true, false, nullptr); }
       else { if (dyn) CFR_LAUNCH_SEARCH(2, false, true, true, nullptr); else CFR_LAUNCH_SEARCH(2, false, true, false, nullptr); }

@@ -35,18 +35,13 @@ BUDGET = {
     "k_search_chains_v2<2, false, true, true>": (128, 0),
     "k_search_chains_v2<4, false, true, false>": (128, 0),
     "k_search_chains_v2<4, false, true, true>": (128, 0),
-    # the instantiations that start a search with the K-mer count table (round 5, CFR_KTAB=1: profiles/r5z_ktab_model.txt)
-    "k_search_chains_v2<2, false, true, false, true>": (128, 0),
-    "k_search_chains_v2<2, false, true, true, true>": (128, 0),
-    "k_search_chains_v2<4, false, true, false, true>": (128, 0),
-    "k_search_chains_v2<4, false, true, true, true>": (128, 0),
     # the two-launch form (round 6, CFR_SEARCH_SPLIT=1: profiles/r6c_ab_stage_split.txt): stage 1 has no wide text mode and no LDS and must keep
     # 5 waves per SIMD; stage 2 is the full state machine over the list
-    "k_search_chains_v2<2, false, false, false, false, 1>": (96, 0),
-    "k_search_chains_v2<2, false, false, true, false, 1>": (96, 0),
-    "k_search_chains_v2<2, false, false, false, false, 2>": (96, 0),
-    "k_search_chains_v2<4, false, false, true, false, 1>": (128, 0),
-    "k_search_chains_v2<4, false, false, true, false, 2>": (128, 0),
+    "k_search_chains_v2<2, false, false, false, 1>": (96, 0),
+    "k_search_chains_v2<2, false, false, true, 1>": (96, 0),
+    "k_search_chains_v2<2, false, false, false, 2>": (96, 0),
+    "k_search_chains_v2<4, false, false, true, 1>": (128, 0),
+    "k_search_chains_v2<4, false, false, true, 2>": (128, 0),
     # translated search: the default instantiation has none; the 80-register one (6 blocks per CU) spills two loop invariants
     "k_search_prot_sm<1, 1>": (96, 0),
     "k_search_prot_sm<2, 1>": (96, 0),
@@ -98,8 +93,7 @@ def probe(kernels, tmp, name, defines=()):
     out = {}
     for mangled, dem in zip(rows, names):
         dem = re.sub(r"^void ", "", re.sub(r"\(.*", "", dem)).replace("cfr::", "")
-        dem = re.sub(r"(k_search_chains_v2<.*), 0>", r"\1>", dem)                         # (the sixth parameter, STAGE, at its default)
-        dem = re.sub(r"(k_search_chains_v2<\d, \w+, \w+, \w+), false>", r"\1>", dem)      # (the fifth parameter, KTAB, at its default)
+        dem = re.sub(r"(k_search_chains_v2<\d, \w+, \w+, \w+), 0>", r"\1>", dem)      # (the fifth parameter, STAGE, at its default)
         out[dem] = (rows[mangled]["VGPRs"], rows[mangled]["ScratchSize"], rows[mangled]["Occupancy"])
     return out
 
