@@ -1194,6 +1194,11 @@ void DeviceIndex::dust_on_device(uint8_t *d_bases, const uint64_t *d_offs, size_
     uint32_t *list = (uint32_t *)(flags + flag_bytes);
     unsigned long long *list_cnt = (unsigned long long *)pool + 2;
     k_dust_flags<<<std::min<unsigned>((unsigned)((n + 255) / 256), (unsigned)(num_cus_ * 16)), 256, 0, st>>>(d_bases, d_offs, n, flags, list, list_cnt);
+    // the screen (round 6): reads in which no triplet occurs six times inside 62 consecutive ones cannot hold a perfect interval; k_dust<true> skips them.
+    // Not for long reads (nearly every one has such a window somewhere): CFR_DUST_SCREEN=0 / 1 forces it off / on
+    static const int screen_env = dbg_env("CFR_DUST_SCREEN") ? atoi(dbg_env("CFR_DUST_SCREEN")) : -1;
+    const bool screen = screen_env >= 0 ? screen_env != 0 : dust_mean_len_ < 600.0;
+    if (screen) k_dust_screen<<<std::min<unsigned>((unsigned)((n + 255) / 256), (unsigned)(num_cus_ * 8)), 256, 0, st>>>(d_bases, d_offs, n, flags);
     // one after the other: side by side (second stream) the 125-triplet blocks take the LDS first and both get slower
     // (measured: 10.5 ms against 10.85 with 14 % flagged reads, 12.5 ms with its grid cut to the flagged count)
     k_dust<true><<<blocks_pure, kDustBlock, 0, st>>>(d_bases, d_offs, n, pool, 0, flags, nullptr, nullptr);
@@ -1224,6 +1229,7 @@ void DeviceIndex::dust_mask_host(uint8_t *bases, const uint64_t *offs, size_t n)
   uint64_t *d_o = (uint64_t *)scratch(S_IN_O1, (n + 1) * 8);
   if (total) HIP_CHECK(hipMemcpyAsync(d_b, bases, total, hipMemcpyHostToDevice, stream_));
   HIP_CHECK(hipMemcpyAsync(d_o, offs, (n + 1) * 8, hipMemcpyHostToDevice, stream_));
+  dust_mean_len_ = (double)total / (double)n;
   dust_on_device(d_b, d_o, n, stream_);
   if (total) HIP_CHECK(hipMemcpyAsync(bases, d_b, total, hipMemcpyDeviceToHost, stream_));
   HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1380,6 +1386,7 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   // 10 M reads against 25.8 ms up front (the search kernel issues ~60 % of its VALU slots itself, so the mask kernel beside it
   // slows both; with host inputs the same overlap pays because the link, not the kernels, bounds the step).
   const bool dust_here = dust_ && !src && !view_.prot.enabled;      // (a protein index takes the reads as they are: CentrifugerClass.cpp:276)
+  dust_mean_len_ = n ? (double)(total1 + total2) / (double)(n * (d_b2 ? 2 : 1)) : 0.0;
   bool dust_pieces = false;
   if (const char *e = dbg_env("CFR_DUST_PIECES")) dust_pieces = dust_here && !search_v1_ && stride > 0 && one_launch_ready() && atoi(e) != 0;
   const uint8_t *orig_b1 = d_b1, *orig_b2 = d_b2;

@@ -263,6 +263,7 @@ class DeviceIndex {
   int num_cus_ = 256, blocks_per_cu_ = 7;
   uint64_t *packed1_ = nullptr, *packed2_ = nullptr;
   uint64_t nblk1_ = 0, nblk2_ = 0;
+  double dust_mean_len_ = 0.0;          // mean read length of the batch being masked (dust_on_device: the screen is for short reads)
   bool search_split_default_ = false;   // the two-launch search (lookup stage + list stage) without CFR_SEARCH_SPLIT
   bool search_v1_ = false, fused_tail_ = true, fused_post_ = true, dust_ = false, team_tail_ = true;
   bool wide_ = false;                  // n >= 2^32: 36-bit SA entries and the WIDE search kernel
