@@ -1739,6 +1739,34 @@ def main():
                     os.unlink(tsv_path)
                 except Exception as e:
                     out["e2e_cli_100m"] = {"error": repr(e)}
+                # ---- the same 100 M reads as FASTQ (what sequencers write: twice the bytes, four lines per record)
+                try:
+                    bigq = os.path.join(cache, "e2e_100m.fq")
+                    lines = open(files[1], "rb").read().split(b"\n")
+                    recs = []
+                    for j in range(0, len(lines) - 1, 2):
+                        recs.append(b"@" + lines[j][1:] + b"\n" + lines[j + 1] + b"\n+\n" + b"I" * len(lines[j + 1]) + b"\n")
+                    blob = b"".join(recs)
+                    del lines, recs
+                    with open(bigq, "wb") as fo:
+                        for _ in range(reps):
+                            fo.write(blob)
+                    del blob
+                    t0 = time.time()
+                    with open(tsv_path, "wb") as fo:
+                        subprocess.run([cli, "-x", prefix, "-t", str(min(ncpu, 64)), "-k", str(k), "-u", bigq], check=True, stdout=fo, stderr=subprocess.DEVNULL)
+                    t_bigq = time.time() - t0
+                    h_got = hashlib.md5()
+                    with open(tsv_path, "rb") as fi:
+                        for chunk in iter(lambda: fi.read(1 << 24), b""):
+                            h_got.update(chunk)
+                    out["e2e_cli_100m_fastq"] = {"reads": nb * reps, "seconds": t_bigq, "value": nb * reps / t_bigq, "unit": "reads/s",
+                                                 "md5_equals_reference_rows": h_got.hexdigest() == h_want.hexdigest(),
+                                                 "note": "the same reads as a plain FASTQ file (30 GB) through `centrifuger -x idx -u 100M.fq -t 64 > file`, wall clock of the process"}
+                    os.unlink(bigq)
+                    os.unlink(tsv_path)
+                except Exception as e:
+                    out["e2e_cli_100m_fastq"] = {"error": repr(e)}
     # ---- the other BASELINE configs on the same index, as sub-results (configs[2] paired-end -k 5, configs[4]-style long reads)
     if world == 1 and args.mode == "se" and not args.no_extra_configs and not args.inner:
         out["other_configs"] = {}

@@ -602,7 +602,7 @@ static size_t format_tsv(const cfr_index *idx, const char *read_id, const cfr_re
     if (expanded) o.ch('\t');
     o.ch('\n');
   }
-  if (buf && o.off < cap) buf[o.off] = '\0';
+  if (buf && cap) buf[o.off < cap ? o.off : cap - 1] = '\0';      // always a C string: a truncated call (return value >= cap: retry with that much + 1) ends at cap - 1
   return o.off;
 }
 

@@ -60,7 +60,7 @@ const char *kUsage =
     "\t--gpu-batch INT: reads per device batch [262144]\n"
     "\t--gpu-balanced: also derive the text-mode tables and the locate memo on the device (+0.4 s load per Gbp, faster kernels)\n"
     "\t--gpu-throughput: ... and the 68 GB K-mer table (longest load, fastest kernels) [default: neither, shortest load]\n"
-    "\t--parse-threads INT: threads that parse plain single-end read files in pieces [min(-t,4); 1 = sequential reader]\n"
+    "\t--parse-threads INT: threads that parse plain single-end read files in pieces [min(-t,8); 1 = sequential reader]\n"
     "\t-h: print this usage message\n"
     "\t-v: print the version information and quit\n";
 
@@ -274,8 +274,13 @@ class SeqReader {
     void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (m == MAP_FAILED) return false;
-    size_t bs = 0;
-    if (!bgzf_header((const uint8_t *)m, (size_t)st.st_size, bs)) { munmap(m, (size_t)st.st_size); return false; }    // a .gz with another extra field
+    // every member must be a BGZF block: a file that continues as a plain gzip member (`cat a.bgz b.gz`) is read like any .gz below,
+    // which is what the reference does with it (kseq + gzread walks concatenated members).  The walk touches one header per block.
+    for (size_t o = 0; o < (size_t)st.st_size;) {
+      size_t bs = 0;
+      if (!bgzf_header((const uint8_t *)m + o, (size_t)st.st_size - o, bs)) { munmap(m, (size_t)st.st_size); return false; }
+      o += bs;
+    }
     bgzf_base_ = (const uint8_t *)m;
     bgzf_size_ = (size_t)st.st_size;
     bgzf_path_ = path;
@@ -777,6 +782,14 @@ int main(int argc, char *argv[]) {
   if (opt.threads < 1) opt.threads = 1;
   SeqReader::inflate_threads = std::max(1, std::min(opt.threads, 16));
   if (opt.gpu_batch < 1) opt.gpu_batch = 1;
+  {
+    // a batch's match (24 B) and --expand-taxid span (16 B) buffers have max_result slots per read, on the host and on the device: with
+    // -k 4096 the default batch of 262144 reads would be 43 GB of them, zero-filled per recycled batch.  Large -k therefore runs smaller
+    // batches (2 GB of slots at most); the rows do not depend on where a batch ends.
+    const size_t k_slots = (size_t)(opt.params.max_result > 0 ? opt.params.max_result : 4);
+    const size_t by_k = std::max<size_t>(1024, (size_t)(2e9 / (40.0 * (double)k_slots)));
+    if (opt.gpu_batch > by_k) opt.gpu_batch = by_k;
+  }
   const bool paired = !opt.m1.empty() || !opt.inter.empty();
   if (opt.m1.size() != opt.m2.size()) { print_log("ERROR: -1 and -2 must be given the same number of times."); return EXIT_FAILURE; }
   if (opt.u.empty() && !paired) { print_log("Need to use -u/-1/-2/-i to specify input reads."); return EXIT_FAILURE; }

@@ -1803,7 +1803,13 @@ void DeviceIndex::classify_device(const uint8_t *d_b1, const uint64_t *d_o1, con
   }
   ev_ = evs_[0];
   overlap_now_ = false;                     // (the cap on the search's blocks belongs to this call's schedule, not to the entries that follow)
-  if (!expand_end()) classify_device(orig_b1, d_o1, orig_b2, d_o2, n, total1, total2, results, matches, match_cap, match_extent, src, compact);
+  if (!expand_end()) {
+    // the pool of --expand-taxid records was too small: once more with one that holds what this run counted (it counted every record,
+    // those of re-run sub-batches twice, so the second run fits).  Bounded: a pool that still does not fit after three runs is an error.
+    if (++exp_attempt_ > 3) { exp_attempt_ = 0; throw HipError{"the pool of --expand-taxid records did not settle in three runs of the batch", -6}; }
+    ++last_stats_exp_retries_;
+    classify_device(orig_b1, d_o1, orig_b2, d_o2, n, total1, total2, results, matches, match_cap, match_extent, src, compact);
+  } else exp_attempt_ = 0;
 }
 
 void DeviceIndex::classify_host(const uint8_t *b1, const uint64_t *o1, const uint8_t *b2, const uint64_t *o2, size_t n,

@@ -227,6 +227,8 @@ class DeviceIndex {
   void expand_begin();                   // before the kernels of a classify call: pool in place, cursor zero, both views know it
   bool expand_end();                     // behind them: false = the pool was too small (it has been enlarged: run the call again)
   uint64_t exp_cap_ = 0;
+  int exp_attempt_ = 0;                 // runs of the current batch that overflowed the --expand-taxid pool (classify_device repeats the batch: at most three)
+  uint64_t last_stats_exp_retries_ = 0;  // such repeats since the image was made (diagnostics)
  public:
   uint64_t last_slow_reads_ = 0, last_team_reads_ = 0;   // of the last one-launch call: reads k_post_fast left to k_adjust_tail / to the team folds
  private:

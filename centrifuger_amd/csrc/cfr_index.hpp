@@ -22,9 +22,9 @@ namespace cfr {
 // Words of a bit string of the index.  Round 5: they stay where they are - in the read-only mapping of the .1.cfr file, which
 // HostIndex keeps for its lifetime - instead of being copied into this process (a 40 Gbp index holds 15 GB of them: eight ranks of one
 // node each made their own copy at once, 6.3 s per open against 2.5 s alone and 120 GB of host memory; mapped, the ranks share the
-// page cache's pages and an open costs the headers).  A string that is not 8-byte aligned in the file, and every caller that wants
-// its own (CFR_INDEX_COPY=1 behind CFR_DEBUG_ENV, the protein parser), gets a copy as before: a vector whose resize() does not
-// zero-fill first.
+// page cache's pages and an open costs the headers).  Every string is mapped whatever its alignment in the file (words are read
+// bytewise, see data() below); a caller that wants its own (CFR_INDEX_COPY=1 behind CFR_DEBUG_ENV, the protein parser) gets a copy
+// as before: a vector whose resize() does not zero-fill first.  Move-only: a copy would keep p_ pointing into the source's buffer.
 template <class T> struct NoInitAlloc : std::allocator<T> {
   template <class U> struct rebind { using other = NoInitAlloc<U>; };
   template <class U, class... A> void construct(U *p, A &&...a) {
@@ -33,6 +33,11 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 class RawWords {
  public:
+  RawWords() = default;
+  RawWords(const RawWords &) = delete;
+  RawWords &operator=(const RawWords &) = delete;
+  RawWords(RawWords &&) noexcept = default;                  // (a vector's buffer moves with it: p_ stays valid)
+  RawWords &operator=(RawWords &&) noexcept = default;
   // the words as BYTES: a mapped string stands where the file has it, and the .cfr format aligns nothing (a one-byte field in the header
   // leaves every bit string of a nucleotide index at an odd offset), so nothing may take this pointer for a uint64_t array - copies,
   // comparisons and uploads go through it bytewise, single words through operator[]

@@ -302,7 +302,8 @@ cfr_status cfr_dust_mask_batch_literal(uint8_t *bases, const uint64_t *offsets, 
 cfr_status cfr_device_index_set_dust(cfr_dev_index *d, int on);
 cfr_status cfr_dust_mask_device(cfr_dev_index *d, uint8_t *bases, const uint64_t *offsets, size_t n);
 
-/* ResultWriter::Output rows for one read (ResultWriter.hpp:209-240).  Returns bytes needed; writes at most cap. */
+/* ResultWriter::Output rows for one read (ResultWriter.hpp:209-240).  Returns bytes needed (without the NUL); writes at most cap and always
+ * NUL-terminates a non-empty buffer: a return value >= cap means the text was cut at cap - 1 and the caller retries with value + 1. */
 size_t cfr_format_tsv(const cfr_index *idx, const char *read_id, const cfr_result *r, const cfr_match *matches,
                       char *buf, size_t cap);
 const char *cfr_tsv_header(void);

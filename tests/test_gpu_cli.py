@@ -173,3 +173,19 @@ def test_cli_parallel_reader_of_paired_and_interleaved_plain_files(golden_dir, t
     short.write_bytes(b"\n".join(l2[:4 * 150]) + b"\n")
     r = subprocess.run([CLI, "-x", os.path.join(golden_dir, "f6"), "-1", m1, "-2", str(short), "--gpu-batch", "17"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"different number of reads" in r.stderr
+
+
+def test_cli_large_k_with_the_default_batch_size(golden_dir, tmp_path):
+    """-k 4096 (the cap) with the default --gpu-batch: the match buffers have max_result slots per read, so the command line cuts its
+    batches down (2 GB of slots) instead of sizing 262144 x 4096 of them; 200 000 reads, rows in input order and equal to
+    the rows of a small-batch run of the same reads"""
+    import time
+    se = os.path.join(golden_dir, "se.fq")
+    big = tmp_path / "big.fq"
+    big.write_bytes(open(se, "rb").read() * 500)
+    base = [CLI, "-x", os.path.join(golden_dir, "f6"), "-k", "4096", "-t", "8"]
+    want = subprocess.run(base + ["-u", se, "--gpu-batch", "64"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    t0 = time.time()
+    out = subprocess.run(base + ["-u", str(big)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert time.time() - t0 < 120
+    assert out.split(b"\n")[1:-1] == want.split(b"\n")[1:-1] * 500
