@@ -87,6 +87,8 @@ def compact_line(out):
         if v is not None:
             par[k] = v
     line["parity"] = par
+    if g(out, "index_on_ranks", "ranks") is not None:
+        line["index_on_ranks"] = {k: out["index_on_ranks"].get(k) for k in ("ranks", "every_rank_maps_the_file", "copied_bytes_max")}
     st = out.get("stage_ms") or {}
     line["stage_ms"] = {k: _r(st.get(k)) for k in ("search_ms", "tail_ms", "total_ms") if k in st}
     if out.get("classified_fraction") is not None:
@@ -1357,7 +1359,13 @@ def main():
 
     # the ranks part here: nothing below needs the process group (rank 0 goes on alone with the CPU baseline, the live PMC
     # passes and the sub-results - minutes during which the other ranks must not be held, nor rank 0 wait for them at exit)
+    # how every rank holds the index's bit strings: mapped from the one file (the ranks of a node share its pages) or copied
+    mapped_b, copied_b = idx.mapped_bytes()
+    ranks_index = [(int(mapped_b), int(copied_b), float(info.device_bytes))]
     if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_index[0])
+        ranks_index = gathered
         dist.barrier()
         dist.destroy_process_group()
         dist = None
@@ -1371,6 +1379,9 @@ def main():
         "metric": "classified reads/sec (150 bp)", "value": value, "unit": "read pairs/s" if paired else "reads/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "index_on_ranks": {"ranks": len(ranks_index), "mapped_bytes_min": min(r_[0] for r_ in ranks_index), "copied_bytes_max": max(r_[1] for r_ in ranks_index),
+                           "device_image_bytes": ranks_index[0][2],
+                           "every_rank_maps_the_file": all(r_[0] > 0 and r_[1] == 0 for r_ in ranks_index)},
         "config": {"workload": f"{info.n/1e9:.2f} Gbp synthetic index ({args.species}x{args.strains}x{args.genome_len/1e6:g} Mbp), " +
                                (f"{args.reads} long reads (5-20 kbp, mean {total_bases/args.reads:.0f} bp) per step per GPU, -k {k}, inputs resident in HBM" if longmode else
                                 f"{args.reads} x {'2x' if paired else ''}{args.read_len} bp {'PE' if paired else 'SE'} reads per step per GPU, -k {k}, inputs resident in HBM"),

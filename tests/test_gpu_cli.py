@@ -141,6 +141,7 @@ def test_cli_over_distinct_devices(golden_dir):
     want = open(os.path.join(GOLDEN, "tsv", "f6.pe_k5.tsv"), "rb").read()
     base = [CLI, "-x", os.path.join(golden_dir, "f6"), "-1", os.path.join(golden_dir, "pe_1.fq"), "-2", os.path.join(golden_dir, "pe_2.fq"), "-k", "5", "--gpu-batch", "20", "-t", "4"]
     last = str(_device_count() - 1)
+    print(f"distinct devices: {_device_count()} in the box; --gpu all, 0,1 and {last},0")
     for gpus in ("all", "0,1", last + ",0"):
         out = subprocess.run(base + ["--gpu", gpus], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
         assert out == want, gpus
