@@ -19,8 +19,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _torch_initialises_hip_first():
-    """Some GPU tests build their index with torch (tests/test_gpu_scale.py).  When libcfr_hip.so has made the process's first
-    HIP call and torch initialises afterwards, torch can report "No HIP GPUs are available" (seen with `pytest
+    """One GPU test holds its reads in torch tensors (tests/test_gpu_scale.py: the resident entries take device pointers and the C-ABI
+    allocates none; since round 6 every test index is written by the product's writer, not by torch).  When libcfr_hip.so has made the
+    process's first HIP call and torch initialises afterwards, torch can report "No HIP GPUs are available" (seen with `pytest
     tests/test_gpu_parity.py tests/test_gpu_scale.py`; the other order always works).  So torch goes first, once per session;
     on a box without a GPU this does nothing."""
     try:

@@ -104,11 +104,9 @@ def test_long_lists_of_a_many_strain_index_against_the_oracle(tmp_path, k):
     """40 near-identical strains per species: the best ids of a read run to dozens, the team folds hand such a read to the single-lane
     form (the lists need the ids as an array), and the list of a reported species holds up to 40 strains.  Every field and every
     list against the C oracle (which is pinned to the reference's TSVs by tests/test_oracle_golden_expand.py)."""
-    import torch
-    from centrifuger_amd import indexbuild
     g = synth.make_genomes(4, 40, 30_000, seed=2203, divergence_step=0.0004)
     prefix = str(tmp_path / "idx")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
     n = 30_000
     rs = synth.make_reads(g, n, 150, seed=2204, sub_rate=0.004, n_rate=0.0005)
     r1, r2 = synth.make_pairs(g, 8_000, 125, seed=2205)

@@ -1,5 +1,5 @@
 """Size-independent properties of the HIP path on a mid-size workload (100 Mbp index written on the box by
-centrifuger_amd.indexbuild, 1 M x 150 bp reads + pairs + long reads): what must hold whatever the batch looks like -
+the product's writer cfr_build_index, 1 M x 150 bp reads + pairs + long reads): what must hold whatever the batch looks like -
 permutation equivariance, independence of how a batch is cut (host batches, shards, device sub-batches), determinism -
 plus agreement with the C oracle on random subsamples.  bench.py covers BASELINE's full size (1 Gbp, 10 M reads) with a
 byte comparison against the reference binary on 2 M reads.  Bit-exact everywhere.  -m gpu only."""
@@ -40,12 +40,10 @@ def digest(sc, slots):
 
 @pytest.fixture(scope="module")
 def world(tmp_path_factory):
-    import torch
     d = str(tmp_path_factory.mktemp("scale"))
     g = synth.make_genomes(25, 4, 1_000_000, seed=4242)
-    from centrifuger_amd import indexbuild
     prefix = os.path.join(d, "idx")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
     reads = synth.make_reads(g, N_READS, READ_LEN, seed=77, sub_rate=0.01, n_rate=0.001)
     r1, r2 = synth.make_pairs(g, 200_000, 125, seed=78)
     longs = synth.make_long_reads(g, 3000, 2000, 12000, seed=79)
@@ -183,12 +181,10 @@ def test_many_near_identical_strains_general_fold(tmp_path):
     """20 strains per species at 0.1 % steps: ranges of 10-40 rows per hit, so nearly every read takes the general form of
     the per-read fold (hash table in pool scratch, pool growth on the way).  Cross-checked against the sort-based fold of the
     two-kernel path on every read, against the plain FM-index walk, and against the C oracle on a subsample."""
-    import torch
-    from centrifuger_amd import indexbuild
     k = int(os.environ.get("CFR_TEST_K", "2"))     # (tests/test_gpu_variants.py runs this with -k 1 and -k 5 too: LCA by the team, listings)
     g = synth.make_genomes(8, 20, 60_000, seed=991, divergence_step=0.001)
     prefix = str(tmp_path / "idx")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
     n = 150_000
     rs = synth.make_reads(g, n, 150, seed=992, sub_rate=0.005, n_rate=0.0005)
     idx, dev = _open(prefix, k, {"CFR_POOL_INIT": "1000"})
@@ -217,11 +213,9 @@ def test_families_of_70_strains_team_fold_limits(tmp_path, k):
     enumeration of Classifier.hpp:640-666 (the team kernel's two-pass row sequence); with -k 3 all 70 (more entries than the
     team's table takes: the single-lane form from inside k_tail_heavy, also with the pool too small at first).  Single-end and
     pairs, against the sort-based fold of the two-kernel path on every read and against the C oracle on a subsample."""
-    import torch
-    from centrifuger_amd import indexbuild
     g = synth.make_genomes(3, 70, 30_000, seed=1203, divergence_step=0.0003)
     prefix = str(tmp_path / "idx")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
     n = 60_000
     rs = synth.make_reads(g, n, 150, seed=1204, sub_rate=0.004, n_rate=0.0005)
     r1, r2 = synth.make_pairs(g, 20_000, 125, seed=1205)
@@ -257,7 +251,7 @@ def test_resident_entries_wide_and_compact(world, k):
     """cfr_classify_batch_resident (the entry the bench times) and cfr_classify_batch_resident_compact (the same results in the
     20 + 12 byte layout) against the host-buffer entry: single-end and pairs, reads of mixed lengths; a long read whose score
     does not fit 32 bits comes back flagged CFR_COMPACT_WIDE."""
-    import torch
+    import torch                               # (device memory for the resident entries: the C-ABI takes device pointers, it does not allocate them)
     idx, dev = _open(world["prefix"], k)
     dv = torch.device("cuda")
 
@@ -316,12 +310,10 @@ def test_ragged_reads_fuzz_against_oracle(world, tmp_path):
     """Reads of every length from 1 to 300 at every alignment of the flat buffer (the 16-byte packed blocks and the
     64-character register queue of the search kernel see every phase), with substitutions, N, lower case, pure noise, mates
     of different lengths; all fields against the C oracle."""
-    import torch
-    from centrifuger_amd import indexbuild
     rng = np.random.default_rng(2024)
     g = synth.make_genomes(6, 3, 40_000, seed=515)
     prefix = str(tmp_path / "fz")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=8, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, ftab_chars=8)
     cat = np.concatenate(g.seqs)
     comp = np.zeros(256, dtype=np.uint8)
     for a, b in zip(b"ACGTN", b"TGCAN"):
@@ -473,12 +465,10 @@ def test_k_above_64_lists_every_strain_like_the_reference(tmp_path):
     table holds: the single-lane form with pool scratch), and the reference has no cap on -k (Classifier.hpp:17-38).  TSV of 3000
     reads and 1000 pairs == the reference binary's; -k 4097 is refused before any device work."""
     import subprocess
-    import torch
-    from centrifuger_amd import indexbuild
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     g = synth.make_genomes(2, 90, 20_000, seed=3301, divergence_step=0.00002)
     prefix = str(tmp_path / "idx")
-    indexbuild.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix, device=torch.device("cuda"))
+    capi.build_index(g.names, g.taxids, g.seqs, g.nodes, g.tax_names, prefix)
     rs = synth.make_reads(g, 3000, 150, seed=3302, sub_rate=0.003, n_rate=0.0005)
     r1, r2 = synth.make_pairs(g, 1000, 125, seed=3303)
     synth.write_fastq(rs, str(tmp_path / "r.fq"))
