@@ -20,6 +20,22 @@ CFR_BENCH_DETAIL=$O/${TAG}_bench_detail.json python bench.py > $O/${TAG}_bench.j
 db=$(find $O/${TAG}_trace -name "*.db" | head -1)
 [ -n "$db" ] && python tools/trace_reconcile.py $db $O/${TAG}_trace.json $O/${TAG}_kernel_trace_stats.txt > /dev/null
 rm -rf $O/${TAG}_trace
+# the same command WITHOUT the profiler, for the cross-check the trace alone cannot give (kernels run ~25 % longer under rocprofv3's
+# kernel trace on this box: a trace's per-step sum may exceed the unprofiled step): HIP-event durations of the unprofiled run go on top of the file
+python $ROOT/bench.py --inner --no-cpu-baseline --no-pmc --no-extra-configs --steps 10 --warmup 2 > $O/${TAG}_untraced.json 2> /dev/null
+python - <<PY
+import json
+try:
+    d = json.loads(open("$O/${TAG}_untraced.json").read().strip().splitlines()[-1])
+    st = d.get("stage_ms") or d
+    line = ("# the same command without the profiler: ms_per_step %.3f, HIP events per step: search %.3f (= %.1f us per launch over 10 launches), post stage %.3f\n"
+            % (d["ms_per_step"], st.get("search_ms", float("nan")), 100.0 * st.get("search_ms", float("nan")), st.get("tail_ms", float("nan"))))
+    p = "$O/${TAG}_kernel_trace_stats.txt"
+    body = open(p).read().splitlines(True)
+    open(p, "w").write("".join(body[:2]) + line + "".join(body[2:]))
+except Exception as e:
+    print("untraced run:", e)
+PY
 # PMC passes: one 2 M-read launch per kernel (a single sub-batch, so per-launch counters divide by 2 M reads)
 CFR_SUBBATCH=2000000 CFR_TAPER_FLOOR=0 tools/pmc_passes.sh $O/${TAG}_pmc --no-pmc --no-extra-configs > $O/${TAG}_pmc.log 2>&1
 python tools/pmc_summary.py $O/${TAG}_pmc > $O/${TAG}_pmc_summary.txt 2>> $O/${TAG}_pmc.log
