@@ -70,7 +70,8 @@ def compact_line(out):
                         "l2_hit": _r(roof.get("l2_hit")), "x_reference_algorithm": _r(roof.get("x_reference_algorithm")), "traffic": _r(roof.get("traffic"), 6),
                         "requests_per_read": _r(roof.get("fabric_read_requests_per_read")), "fetched_over_useful": _r(roof.get("fetched_over_useful")),
                         "valu_per_wave_iteration": _r(g(roof, "instruction_stream", "valu_wave_instructions_per_wave_iteration")),
-                        "valu_issue_frac": _r(g(roof, "instruction_stream", "valu_issue_frac")), "kernel_ms_alone": _r(roof.get("kernel_ms_alone"))}
+                        "valu_issue_frac": _r(g(roof, "instruction_stream", "valu_issue_frac")), "valu_time_frac": _r(g(roof, "instruction_stream", "valu_time_frac")),
+                        "kernel_ms_alone": _r(roof.get("kernel_ms_alone"))}
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _r(cb.get("value"), 6), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": (cb.get("sample") or "")[:160],
@@ -655,6 +656,9 @@ def instruction_stream(pmc):
     return {"valu_wave_instructions_per_read": sq["SQ_INSTS_VALU"] / n, "salu_wave_instructions_per_read": (sq["SQ_INSTS_SALU"] / n) if sq.get("SQ_INSTS_SALU") is not None else None,
             "vmem_read_wave_instructions_per_read": (sq["SQ_INSTS_VMEM_RD"] / n) if sq.get("SQ_INSTS_VMEM_RD") is not None else None,
             "valu_issue_frac": sq["SQ_INSTS_VALU"] / (ms / 1e3) / (1024.0 * clock / 2.0), "clock_GHz": clock / 1e9,
+            # (round 6) SQ_ACTIVE_INST_VALU stands at 1.00 QUAD-cycles per vector instruction on this chip (the SDUST pass collects it): a wave64
+            # instruction holds its SIMD for four cycles, so the share of the chip's VALU time this kernel uses is twice the figure above
+            "valu_time_frac": sq["SQ_INSTS_VALU"] / (ms / 1e3) / (1024.0 * clock / 4.0),
             "valu_wave_instructions_per_wave_iteration": (sq["SQ_INSTS_VALU"] * 64.0 / (n * iters)) if iters else None,
             "waves_per_simd": (wc * 4.0 / ((ms / 1e3) * clock * 1024.0)) if wc else None,
             "wave_cycles_waiting": (sq["SQ_WAIT_ANY"] / wc) if wc and sq.get("SQ_WAIT_ANY") is not None else None,
