@@ -159,6 +159,37 @@ def test_classification_with_the_device_pre_step(dev, golden_dir):
     assert int((masked != b).sum()) > 1000
 
 
+def test_resident_reads_at_an_unaligned_device_pointer(dev, golden_dir):
+    """cfr_classify_batch_resident with SDUST on the device and a bases pointer that is not 4-byte aligned (a caller's slice of its own
+    buffer): the screen and the scan fetch aligned words around the read, so the first read's words start BELOW the pointer; the first reads
+    are homopolymers, which a screen that lost its first bases would let through unmasked."""
+    import torch
+    idx, d = dev
+    rng = np.random.default_rng(9)
+    seqs = [b"A" * 9 + bytes(rng.choice(list(b"ACGT"), size=141).astype(np.uint8)), b"ACGT" + b"C" * 8 + bytes(rng.choice(list(b"ACGT"), size=138).astype(np.uint8))]
+    recs = open(os.path.join(golden_dir, "se.fq"), "rb").read().split(b"\n")
+    seqs += [recs[i + 1] for i in range(0, len(recs) - 1, 4)][:200]
+    b = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    o = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    masked = b.copy()
+    capi.dust_mask(masked, o, threads=2)
+    assert (masked[:20] != b[:20]).any()
+    want_r, want_m = d.classify(masked, o)
+    dv = torch.device("cuda")
+    do = torch.from_numpy(o.astype(np.int64)).to(dv)
+    d.set_dust(True)
+    try:
+        for shift in (0, 1, 2, 3):
+            big = torch.zeros(len(b) + 64, dtype=torch.uint8, device=dv)
+            big[shift:shift + len(b)] = torch.from_numpy(b).to(dv)
+            torch.cuda.synchronize()
+            got_r, got_m = d.classify_resident(big.data_ptr() + shift, do.data_ptr(), len(seqs), int(o[-1]))
+            assert got_r.tobytes() == want_r.tobytes() and got_m[:len(want_m)].tobytes() == want_m.tobytes(), shift
+            assert bytes(big[shift:shift + len(b)].cpu().numpy()) == b.tobytes()          # the caller's reads stay as they were
+    finally:
+        d.set_dust(False)
+
+
 def _dust_golden():
     import gzip
     import oracle_lib as ora
