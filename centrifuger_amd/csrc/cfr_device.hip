@@ -434,7 +434,7 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
   }
   {
     // auto K: several K-mers per text position (an unmatched strand then ends inside the lookup; measured: 16 beats 15 on a
-    // 1 Gbp index by 7 % of the search kernel), at least 2 characters wider than the on-disk ftab, at most 16
+    // 1 Gbp index by 7 % of the search kernel), at least 2 characters wider than the on-disk ftab, at most 16 - or 17, below
     uint32_t K = std::min<uint32_t>(16, std::max<uint32_t>(view_.ftab_width + 2, log4n + 2));
     bool e8 = false;
     size_t free_b = 0, total_b = 0;
@@ -443,12 +443,19 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       auto fits = [&](uint32_t k, bool small) { return (double)((small ? 8ull : 16ull) << (2 * k)) + rest <= 0.97 * (double)free_b; };
       while (K > view_.ftab_width + 2 && !fits(K, false) && !fits(K, true)) --K;
       e8 = !fits(K, false);
+      // K = 17 with 8-byte entries (137 GB; round 6) for indexes of 4^14 = 2.7e8 symbols and more, when it fits beside everything else: a
+      // random 17-mer occurs a quarter as often as a 16-mer, and fewer chance matches are fewer suffix-array fetches, text steps, wide
+      // ranges and (36-bit images) extends - it beats K = 16 WITH its 16-byte entries' text positions on every workload measured
+      // (profiles/r6w_ab_k17.txt: 1 Gbp +4.5 %, pairs +3 %, long reads +10 %, 2.5 Gbp +12 %, 8 Gbp +15 % / long +24 %, strains +1 % / 0)
+      static const bool k17_off = dbg_env("CFR_K17") && atoi(dbg_env("CFR_K17")) == 0;
+      if (!k17_off && !fast_load && K == 16 && log4n + 3 >= 17 && view_.ftab_width + 2 <= 17 && fits(17, true)) { K = 17; e8 = true; }
     }
     if (fast_load || balanced) { K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13)); e8 = false; }     // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
     if (const char *e = dbg_env("CFR_FTABX_WIDTH")) K = (uint32_t)atoi(e);
     if (const char *e = dbg_env("CFR_FTABX_E8")) e8 = atoi(e) != 0;        // test hook: the 8-byte entries on a small index
-    if (K > 16) K = 16;
+    if (K > 17) K = 17;                  // (17 only by request - CFR_FTABX_WIDTH - and with 8-byte entries: 137 GB)
+    if (K == 17) e8 = true;
     if (protein) K = 0;                  // derived K-mer table and text mode are nucleotide designs
     if (K > view_.ftab_width && view_.ftab_width > 0) try {
       const uint64_t entries = 1ull << (2 * K);
