@@ -137,8 +137,8 @@ typedef enum { CFR_PROFILE_THROUGHPUT = 0, CFR_PROFILE_FAST_LOAD = 1, CFR_PROFIL
 typedef struct {
   int32_t profile;        /* cfr_profile.  FAST_LOAD: K-mer table of at most 4^13 entries, no text-mode tables, no locate memo
                              (shortest load).  BALANCED: the 4^13 table WITH the text-mode tables and the locate memo (no 68 GB
-                             allocation: what the command line uses).  THROUGHPUT: everything, K up to 16 */
-  int32_t ftabx_width;    /* K of the derived K-mer table; -1 = automatic (log4(n)+2, at most 16, a quarter of the free HBM), 0 = none */
+                             allocation: what the command line uses).  THROUGHPUT: everything, K up to 17 */
+  int32_t ftabx_width;    /* K of the derived K-mer table; -1 = automatic (17 with 8-byte entries - 137 GB - for indexes of 2.7e8 symbols and more when it fits, else log4(n)+2, at most 16), 0 = none */
   int32_t text_mode;      /* derived SA / ISA / 2-bit text (n < 2^32): -1 = by profile, 0 = off, 1 = on */
   int32_t run_block_layout; /* 1 = keep the run-block components compressed in HBM instead of the flat occurrence image */
   double loc_memo_gb;     /* byte budget of the locate memo in GB; negative = by profile (16 / none), 0 = none */
