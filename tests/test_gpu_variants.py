@@ -29,7 +29,6 @@ VARIANTS = {
     # round 6: the table the large indexes get by default - K = 17, 8-byte entries (34-bit keys; 137 GB whatever the index) - on the golden reads
     "ftabx_k17": {"CFR_FTABX_WIDTH": "17", "CFR_FTABX_E8": "1"},
     # ... and the two-launch search (stage 1 without wide text mode + stage 2 over the list: off by default, kept measurable)
-    "search_split": {"CFR_SEARCH_SPLIT": "1"},
     "search_split_many_subbatches_wave_tiles": {"CFR_SEARCH_SPLIT": "1", "CFR_SEARCH_DYN": "2", "CFR_SUBBATCH": "53", "CFR_TAPER_FLOOR": "0"},
     # the sampled rows "do not follow" the step function: no text mode, locate memo by the plain walk
     "step_function_rejected": {"CFR_STEPS_OFF": "1"},
@@ -95,7 +94,7 @@ def test_parity_suite_under_switches(name):
                                         ("post_stage_never_overlapped", {"CFR_TAIL_STREAM": "0", "CFR_SUBBATCH": "20000"}),
                                         ("post_fast", {"CFR_POST_FAST": "1", "CFR_SUBBATCH": "20000"}), ("post_fast_k5", {"CFR_POST_FAST": "1", "CFR_TEST_K": "5"}),
                                         ("search_wave_tiles", {"CFR_SEARCH_DYN": "2", "CFR_SUBBATCH": "20000"}), ("search_static", {"CFR_SEARCH_DYN": "0"}),
-                                        ("search_split", {"CFR_SEARCH_SPLIT": "1", "CFR_SUBBATCH": "20000"}), ("search_split_wide_tables", {"CFR_SEARCH_SPLIT": "1", "CFR_FORCE_WIDE": "1"})])
+                                        ("search_split", {"CFR_SEARCH_SPLIT": "1", "CFR_SUBBATCH": "20000"})])
 def test_many_strain_workload_under_switches(name, extra):
     """The 20-strain workload (ranges of up to 20 rows: wide text mode, hash fold) of tests/test_gpu_scale.py with the 5-byte
     tables forced (the WIDE kernel's wide text mode on a small index) and with wide text mode off."""
