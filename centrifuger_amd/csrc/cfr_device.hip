@@ -448,7 +448,10 @@ void DeviceIndex::init(const HostIndex &h, const cfr_device_options &opt) {
       // ranges and (36-bit images) extends - it beats K = 16 WITH its 16-byte entries' text positions on every workload measured
       // (profiles/r6w_ab_k17.txt: 1 Gbp +4.5 %, pairs +3 %, long reads +10 %, 2.5 Gbp +12 %, 8 Gbp +15 % / long +24 %, strains +1 % / 0)
       static const bool k17_off = dbg_env("CFR_K17") && atoi(dbg_env("CFR_K17")) == 0;
-      if (!k17_off && !fast_load && K == 16 && log4n + 3 >= 17 && view_.ftab_width + 2 <= 17 && fits(17, true)) { K = 17; e8 = true; }
+      // (with room to spare: at 16 Gbp the 137 GB fit by the estimate above and left a 10 M-read batch no scratch - 287 GB of image, hipMalloc
+      //  out of memory in the first call; the load's other tables are ~4.5 bytes per symbol more than `rest` counts.  K = 17 up to ~11 Gbp.)
+      const bool room17 = (double)(8ull << 34) + rest + 4.5 * (double)h.n + 20e9 <= 0.97 * (double)free_b;
+      if (!k17_off && !fast_load && K == 16 && log4n + 3 >= 17 && view_.ftab_width + 2 <= 17 && room17) { K = 17; e8 = true; }
     }
     if (fast_load || balanced) { K = std::min<uint32_t>(K, std::max<uint32_t>(view_.ftab_width + 2, 13)); e8 = false; }     // <= 1 GB
     if (opt.ftabx_width >= 0) K = (uint32_t)opt.ftabx_width;
